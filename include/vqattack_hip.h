@@ -1,0 +1,166 @@
+/*
+ * vqattack_hip.h -- C ABI of the MI355X (gfx950) kernels behind VQAttack's PGD hot path.
+ *
+ * Boundary contract (last row): plain device pointers, element / row counts,
+ * scalars and a hipStream_t; every entry point returns an int (0 = VQA_OK, otherwise a negative VQA_ERR_*
+ * or a positive hipError_t), never allocates, never synchronises and never touches the host side of
+ * its buffers, so a caller may capture any sequence of them into a hipGraph.  All tensors are fp32,
+ * contiguous unless strides are passed explicitly.  "Reference" below is ericyinyzy/VQAttack; paths are
+ * relative to its root, A-ch = ALBEF_VQAttack/cleverhans/cleverhans/torch, V-ch = the VLMO_VQAttack copy.
+ *
+ * The library is loaded by vqattack_amd/_hip.py (ctypes); INTEGRATION.md shows the stub a maintainer
+ * of the reference would add to call it from the reference's own cleverhans modules.
+ */
+#ifndef VQATTACK_HIP_H
+#define VQATTACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vqa_stream_t; /* a hipStream_t (NULL = the legacy default stream) */
+
+#define VQA_OK 0
+#define VQA_ERR_NULL (-1)     /* a required pointer is NULL */
+#define VQA_ERR_SHAPE (-2)    /* a count/stride argument is out of the supported range */
+#define VQA_ERR_ALIGN (-3)    /* a pointer that must be 4-byte aligned is not */
+
+/* mode bits shared by the image-update entry points */
+#define VQA_CLIP 1u           /* clamp the result to [cmin, cmax] (the reference's clip_min/clip_max not None) */
+#define VQA_CHECK_RANGE 2u    /* atomically OR 1 into *flag when an INPUT x element is outside [cmin, cmax] or NaN
+                                 (reference: torch.all(ge(x, clip_min)) / le(x, clip_max) sanity flags,
+                                 A-ch/attacks/projected_gradient_descent.py:95-105) */
+
+int vqa_abi_version(void);
+const char* vqa_error_string(int code);
+
+/* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
+ *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
+ *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1) */
+int vqa_set_option(int option, int value);
+
+/* ---------------------------------------------------------------- L-infinity image update (hot)
+ * sign(g) follows torch.sign: sign(+-0) = 0, sign(NaN) = 0.  clamp propagates NaN like torch.clamp.
+ * All four are pure elementwise streams; `out` may alias `x` (in-place) but no other aliasing.
+ */
+
+/* PGD start point: out = clamp(x + clamp(eta, -eps, eps), cmin, cmax); eta == NULL means eta = 0.
+ * Replaces A-ch/attacks/projected_gradient_descent.py:110-120 (+ the range flags :95-105). 8-12 B/element. */
+int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float eps, float cmin, float cmax,
+                  unsigned mode, int* flag, vqa_stream_t stream);
+
+/* FGM update only: out = clamp(x + eps_iter * sign(g), cmin, cmax).
+ * Replaces A-ch/utils.py:86,127 + A-ch/attacks/fast_gradient_method.py:151-160. 12 B/element. */
+int vqa_linf_fgm(const float* x, const float* g, float* out, size_t n, float eps_iter, float cmin, float cmax,
+                 unsigned mode, int* flag, vqa_stream_t stream);
+
+/* Fused PGD iteration tail (the north-star kernel): FGM update, then projection on the eps-ball around x0:
+ *   a   = clamp(x + eps_iter * sign(g), cmin, cmax)
+ *   e   = clamp(a - x0, -eps, eps)
+ *   out = clamp(x0 + e, cmin, cmax)
+ * Replaces rows 5-8 and 10-13 of SURVEY.md section 2.3 (A-ch/attacks/fast_gradient_method.py:151-160 +
+ * A-ch/attacks/projected_gradient_descent.py:146-151). 16 B/element (reads x, g, x0; writes out). */
+int vqa_linf_step(const float* x, const float* g, const float* x0, float* out, size_t n, float eps_iter,
+                  float eps, float cmin, float cmax, unsigned mode, int* flag, vqa_stream_t stream);
+
+/* Projection only: out = clamp(x0 + clamp(adv - x0, -eps, eps), cmin, cmax).
+ * Replaces A-ch/attacks/projected_gradient_descent.py:146-151 on its own. 12 B/element. */
+int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, float eps, float cmin,
+                     float cmax, unsigned mode, vqa_stream_t stream);
+
+/* clip_eta(norm=inf): out = clamp(eta, -eps, eps).  A-ch/utils.py:21. */
+int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream);
+
+/* optimize_linear(norm=inf): out = eps * sign(g).  A-ch/utils.py:86,127. */
+int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------- per-sample reductions (L2 / L1 norms)
+ * Deterministic two-stage reductions: stage 1 writes per-block partials into `ws`, stage 2 combines them in a
+ * fixed order, so results are bitwise reproducible run to run.  `ws` must hold vqa_reduce_ws_bytes() bytes.
+ */
+size_t vqa_reduce_ws_bytes(int batch, size_t n_per_sample);
+
+/* out[b] = sum_i (t[b,i] - (sub ? sub[b,i] : 0))^2.   A-ch/utils.py:33-35 and :106. 4-8 B/element. */
+int vqa_sumsq_per_sample(const float* t, const float* sub, float* out, int batch, size_t n_per_sample,
+                         float* ws, vqa_stream_t stream);
+
+/* amax[b] = max_i |g[b,i]|, ties[b] = #{i : |g[b,i]| == amax[b]}.  A-ch/utils.py:95-100.  */
+int vqa_absmax_ties_per_sample(const float* g, float* amax, float* ties, int batch, size_t n_per_sample,
+                               float* ws, vqa_stream_t stream);
+
+/* FGM update, L2:  out = clamp(x + eps_iter * (g / sqrt(max(1e-12, sumsq_g[b]))), cmin, cmax).
+ * A-ch/utils.py:106-107,127 + fast_gradient_method.py:152-160. */
+int vqa_l2_fgm(const float* x, const float* g, const float* sumsq_g, float* out, int batch,
+               size_t n_per_sample, float eps_iter, float cmin, float cmax, unsigned mode, int* flag,
+               vqa_stream_t stream);
+
+/* Projection, L2: eta = adv - x0; eta *= min(1, eps / sqrt(max(1e-12, sumsq_eta[b]))); out = clamp(x0 + eta).
+ * A-ch/utils.py:31-39 + projected_gradient_descent.py:146-151. */
+int vqa_l2_project(const float* adv, const float* x0, const float* sumsq_eta, float* out, int batch,
+                   size_t n_per_sample, float eps, float cmin, float cmax, unsigned mode, vqa_stream_t stream);
+
+/* FGM update, L1: out = clamp(x + eps_iter * sign(g) * [|g| == amax[b]] / ties[b], cmin, cmax).
+ * A-ch/utils.py:88-101,127. */
+int vqa_l1_fgm(const float* x, const float* g, const float* amax, const float* ties, float* out, int batch,
+               size_t n_per_sample, float eps_iter, float cmin, float cmax, unsigned mode, int* flag,
+               vqa_stream_t stream);
+
+/* Per-sample scaling used by the stand-alone utils:
+ *   kind 0 (clip_eta, norm=2):        out = t * min(1, eps / sqrt(max(1e-12, stat[b])))           A-ch/utils.py:31-39
+ *   kind 1 (optimize_linear, norm=2): out = eps * (t / sqrt(max(1e-12, stat[b])))                 A-ch/utils.py:106-107,127
+ *   kind 2 (optimize_linear, norm=1): out = eps * (sign(t) * [|t| == stat[b]] / stat2[b])         A-ch/utils.py:88-101,127
+ */
+int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, float* out, int batch,
+                         size_t n_per_sample, float eps, int kind, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------- cross-modal loss reduction
+ * Rows of D contiguous floats, addressed as row(o, i) = base + o*stride0 + i*stride1 (strides in ELEMENTS) for
+ * o < rows0, i < rows1 -- this is how the reference's `out[k][:, :feat_len, :]` truncation views are consumed
+ * without a copy.  For every row pair:  c = sum_d (a_d / max(|a|, cos_eps)) * (b_d / max(|b|, cos_eps))
+ * (torch.nn.CosineSimilarity semantics of torch 2.x).  The kernel accumulates  -c  per block into
+ * partial[] and, when ga != NULL, writes d(gscale * sum(-c)) / d a  into ga (same addressing as a, with its own
+ * strides) -- loss value and the gradient w.r.t. the model output in ONE pass over a and b.
+ * row_mask (nullable, uint8): rows with row_mask[(o % mask_period) * rows1 + i] == 0 contribute nothing and get a
+ * zero gradient (padded text tokens of a batched VLMO adapter).
+ * Replaces nn.CosineSimilarity + negate + two torch.sum calls and their autograd backward:
+ * A-ch/attacks/fast_gradient_method.py:98,120-127; V-ch/attacks/fast_gradient_method.py:102-114.
+ * D must be a multiple of 4 and <= 2048; a, b, ga 16-byte aligned with strides multiples of 4.
+ * Algorithmic bytes: 8*D per row (loss only) or 12*D per row (loss + gradient).
+ * `partial` must hold vqa_neg_cos_partials() floats.
+ */
+int vqa_neg_cos_partials(void);
+int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, const uint8_t* row_mask,
+                     long mask_period, long rows0, long rows1, int D, long a_stride0, long a_stride1,
+                     long b_stride0, long b_stride1, long g_stride0, long g_stride1, float gscale,
+                     float cos_eps, vqa_stream_t stream);
+
+/* dst[0] = (accumulate ? dst[0] : 0) + scale * sum_{i<count} partial[i], summed in index order by one workgroup.
+ * Turns the partials of one or more vqa_neg_cos_rows launches into the scalar loss on the device
+ * (the reference's float(loss.cpu()) host sync per step, projected_gradient_descent.py:145, is deferred). */
+int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
+                     vqa_stream_t stream);
+
+/* ---------------------------------------------------------------- text side
+ * dst[b, k, :] = src[b, idx[k], :]  for src (B, L, D), idx int64[K] with 0 <= idx[k] < L.
+ * Replaces `x[1].grad[:, text_emb_pick]`, A-ch/attacks/fast_gradient_method_vl.py:120 (V-ch: :130). */
+int vqa_gather_rows(const float* src, const int64_t* idx, float* dst, int B, int L, int K, int D,
+                    vqa_stream_t stream);
+
+/* Candidate-substitution scoring (update_adv_text + dir_sim, ALBEF_attack/adv_attack.py:284-298,325-333;
+ * vlmo_module.py:1632-1702).  For candidate c with (sample s, token position p, gradient row k, vocabulary id v):
+ *   e   = LayerNorm(word[v] + pos[p] + type[0]; gamma, beta, ln_eps)         (BERT embeddings, position-wise)
+ *   d   = e - e_ori[s, p]
+ *   out[c] = cos( d / max(|d|, 1e-12),  g / max(|g|, 1e-12) ; eps = 1e-6 ),   g = grad[s, k]
+ * cand is int32[n_cand][4] = {s, p, k, v}.  word (V, D), pos (P, D), type (>=1, D), e_ori (S, L, D), grad (S, K, D).
+ * D multiple of 4, <= 2048. */
+int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, const float* gamma,
+                     const float* beta, float ln_eps, const float* e_ori, const float* grad,
+                     const int32_t* cand, float* out, int n_cand, int L, int K, int D, vqa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQATTACK_HIP_H */

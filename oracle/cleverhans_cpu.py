@@ -368,3 +368,29 @@ def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, cli
         adv = _project(adv, ori_x, norm, eps, clip_min, clip_max)
     _final_asserts(flags, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)
     return adv, text_grad
+
+
+# --------------------------------------------------------------------------- kernel-level checkers
+def fgm_update_given_grad(x, grad, eps, norm, clip_min=None, clip_max=None):
+    """Rows 5-8 of SURVEY.md section 2.3 for a GIVEN gradient: clamp(x + optimize_linear(grad, eps, norm))."""
+    return _finish_step(x, grad, eps, norm, clip_min, clip_max)
+
+
+def pgd_tail_given_grad(x, grad, ori_x, eps_iter, eps, norm, clip_min=None, clip_max=None):
+    """Rows 5-8 + 10-13 for a GIVEN gradient: the FGM update followed by the eps-ball projection, i.e. what the
+    reference computes between two model calls (fast_gradient_method.py:151-160 + projected_gradient_descent.py:146-151)."""
+    return _project(_finish_step(x, grad, eps_iter, norm, clip_min, clip_max), ori_x, norm, eps, clip_min, clip_max)
+
+
+def start_point(x, eta, norm, eps, clip_min=None, clip_max=None):
+    """projected_gradient_descent.py:117-120 for a given eta (None = zeros)."""
+    eta = torch.zeros_like(x) if eta is None else eta.clone()
+    adv = x + clip_eta(eta, norm, eps)
+    if clip_min is not None or clip_max is not None:
+        adv = torch.clamp(adv, clip_min, clip_max)
+    return adv
+
+
+def range_ok(x, clip_min, clip_max):
+    """The sanity flags of projected_gradient_descent.py:95-105 as one bool."""
+    return bool(np.all([bool(f) for f in _range_flags(x, clip_min, clip_max)]))

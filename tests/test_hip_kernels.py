@@ -1,0 +1,328 @@
+"""Kernel-level parity: HIP entry points (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: BIT-EXACT for the L-infinity family (adds, clamps, multiply by +-1/0 -- correctly rounded, same order as the
+reference's eager chain).  The L2/L1 family and the cosine loss involve reductions whose summation order differs from
+ATen's, so they are held to the fp32 tolerances written next to each assert (relative 2e-6 on per-sample norms,
+which propagates to <= 1e-6 absolute on perturbations of magnitude <= 1; 1e-5 relative on the loss).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cleverhans_cpu as o
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from vqattack_amd import ops
+    return ops
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    r = np.random.RandomState(seed)
+    return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32))
+
+
+def _grad(shape, seed):
+    r = np.random.RandomState(seed)
+    g = r.standard_normal(shape).astype(np.float32)
+    flat = g.reshape(-1)
+    n = flat.size
+    idx = r.choice(n, size=max(n // 50, 4), replace=False)
+    flat[idx[0::4]] = 0.0
+    flat[idx[1::4]] = -0.0
+    flat[idx[2::4]] = np.nan
+    flat[idx[3::4]] = np.float32(1e-42)       # denormal: sign must still be +1
+    return torch.from_numpy(g)
+
+
+def _same_bits(a, b):
+    a = a.detach().cpu().numpy().view(np.uint32)
+    b = b.detach().cpu().numpy().view(np.uint32)
+    return np.array_equal(a, b)
+
+
+SHAPES = [(4, 3, 384, 384), (2, 3, 32, 32), (1, 3, 5, 7), (3, 1, 1, 1), (1, 1, 1, 2)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(s) for s in SHAPES])
+@pytest.mark.parametrize("eps,eps_iter", [(0.125, 0.01), (8 / 255, 2 / 255)])
+def test_linf_step_bitexact(shape, eps, eps_iter):
+    ops = _ops()
+    x0 = _rand(shape, 1)
+    x = torch.clamp(x0 + _rand(shape, 2, -eps, eps), -1, 1)
+    g = _grad(shape, 3)
+    want = o.pgd_tail_given_grad(x, g, x0, eps_iter, eps, np.inf, -1, 1)
+    got = ops.linf_step(x.to(DEV), g.to(DEV), x0.to(DEV), eps_iter, eps, -1, 1)
+    assert _same_bits(got, want)
+    # without clipping
+    want = o.pgd_tail_given_grad(x, g, x0, eps_iter, eps, np.inf)
+    got = ops.linf_step(x.to(DEV), g.to(DEV), x0.to(DEV), eps_iter, eps, None, None)
+    assert _same_bits(got, want)
+
+
+def test_linf_step_nan_inputs_and_inplace():
+    ops = _ops()
+    shape = (2, 3, 16, 16)
+    x0 = _rand(shape, 4)
+    x = torch.clamp(x0 + _rand(shape, 5, -0.125, 0.125), -1, 1)
+    x.view(-1)[7] = float("nan")
+    x0.view(-1)[11] = float("nan")
+    g = _grad(shape, 6)
+    want = o.pgd_tail_given_grad(x, g, x0, 0.01, 0.125, np.inf, -1, 1)
+    xd = x.to(DEV)
+    got = ops.linf_step(xd, g.to(DEV), x0.to(DEV), 0.01, 0.125, -1, 1, out=xd)   # in place
+    assert got.data_ptr() == xd.data_ptr()
+    assert _same_bits(got, want)
+
+
+def test_linf_unaligned_views_take_scalar_path():
+    ops = _ops()
+    n = 4099
+    base_x, base_g, base_0 = _rand((n + 1,), 7), _grad((n + 1,), 8), _rand((n + 1,), 9)
+    x, g, x0 = base_x[1:], base_g[1:], base_0[1:]          # 4-byte aligned only
+    want = o.pgd_tail_given_grad(x.clone(), g.clone(), x0.clone(), 0.01, 0.125, np.inf, -1, 1)
+    xd, gd, x0d = base_x.to(DEV)[1:], base_g.to(DEV)[1:], base_0.to(DEV)[1:]
+    out = torch.empty(n + 1, device=DEV)[1:]
+    from vqattack_amd import _hip
+    _hip.check(_hip.lib().vqa_linf_step(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(x0d), _hip.ptr(out), n, 0.01, 0.125,
+                                        -1.0, 1.0, 1, None, _hip.stream_for(xd)), "vqa_linf_step")
+    assert _same_bits(out, want)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3], ids=[str(s) for s in SHAPES[:3]])
+def test_linf_fgm_init_project_bitexact(shape):
+    ops = _ops()
+    x0 = _rand(shape, 10)
+    eta = _rand(shape, 11, -0.3, 0.3)
+    g = _grad(shape, 12)
+    x = torch.clamp(x0 + torch.clamp(eta, -0.125, 0.125), -1, 1)
+    assert _same_bits(ops.linf_fgm(x.to(DEV), g.to(DEV), 0.01, -1, 1), o.fgm_update_given_grad(x, g, 0.01, np.inf, -1, 1))
+    assert _same_bits(ops.linf_fgm(x.to(DEV), g.to(DEV), 0.01, None, None), o.fgm_update_given_grad(x, g, 0.01, np.inf))
+    assert _same_bits(ops.linf_init(x0.to(DEV), eta.to(DEV), 0.125, -1, 1), o.start_point(x0, eta, np.inf, 0.125, -1, 1))
+    assert _same_bits(ops.linf_init(x0.to(DEV), None, 0.125, -1, 1), o.start_point(x0, None, np.inf, 0.125, -1, 1))
+    far = x0 + eta * 3
+    assert _same_bits(ops.linf_project(far.to(DEV), x0.to(DEV), 0.125, -1, 1), o._project(far, x0, np.inf, 0.125, -1, 1))
+
+
+def test_range_flag():
+    ops = _ops()
+    x = _rand((2, 3, 8, 8), 13)
+    flag = ops.new_flag(DEV)
+    ops.linf_init(x.to(DEV), None, 0.1, -1, 1, flag=flag)
+    assert int(flag.item()) == 0 and o.range_ok(x, -1, 1)
+    for bad in (1.5, -1.0001, float("nan")):
+        xb = x.clone()
+        xb.view(-1)[17] = bad
+        flag = ops.new_flag(DEV)
+        ops.linf_init(xb.to(DEV), None, 0.1, -1, 1, flag=flag)
+        assert int(flag.item()) == 1 and not o.range_ok(xb, -1, 1)
+        flag = ops.new_flag(DEV)
+        ops.linf_step(xb.to(DEV), x.to(DEV), x.to(DEV), 0.01, 0.1, -1, 1, flag=flag)
+        assert int(flag.item()) == 1
+
+
+def test_utils_linf_bitexact():
+    from vqattack_amd import utils
+    t = _grad((6, 3, 5, 4), 14)
+    assert _same_bits(utils.clip_eta(t.to(DEV), np.inf, 0.5), o.clip_eta(t.clone(), np.inf, 0.5))
+    assert _same_bits(utils.optimize_linear(t.to(DEV), 0.01, np.inf), o.optimize_linear(t.clone(), 0.01, np.inf))
+
+
+# ----------------------------------------------------------------------------- L2 / L1 (tolerance)
+NORM_RTOL = 2e-6
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 384, 384), (3, 3, 5, 7), (2, 1, 1, 3)], ids=str)
+def test_sumsq_and_absmax(shape):
+    ops = _ops()
+    t = torch.from_numpy(np.random.RandomState(15).standard_normal(shape).astype(np.float32))
+    s = _rand(shape, 16)
+    got = ops.sumsq_per_sample(t.to(DEV)).cpu().double()
+    want = (t.double() ** 2).flatten(1).sum(1)
+    assert torch.allclose(got, want, rtol=NORM_RTOL, atol=0)
+    got = ops.sumsq_per_sample(t.to(DEV), sub=s.to(DEV)).cpu().double()
+    want = ((t - s).double() ** 2).flatten(1).sum(1)
+    assert torch.allclose(got, want, rtol=NORM_RTOL, atol=0)
+    t.view(shape[0], -1)[0, 0] = 9.5
+    t.view(shape[0], -1)[0, -1] = -9.5
+    amax, ties = ops.absmax_ties_per_sample(t.to(DEV))
+    want_max = t.abs().flatten(1).max(1).values
+    assert torch.equal(amax.cpu(), want_max)                      # max is exact
+    assert torch.equal(ties.cpu(), (t.abs().flatten(1) == want_max[:, None]).sum(1).float())
+    # determinism: bitwise identical on a second run
+    assert torch.equal(ops.sumsq_per_sample(t.to(DEV)), ops.sumsq_per_sample(t.to(DEV)))
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 384, 384), (3, 3, 5, 7)], ids=str)
+def test_l2_step_tolerance(shape):
+    ops = _ops()
+    x0 = _rand(shape, 17)
+    x = torch.clamp(x0 + _rand(shape, 18, -0.05, 0.05), -1, 1)
+    g = torch.from_numpy(np.random.RandomState(19).standard_normal(shape).astype(np.float32))
+    g[0] = 0.0                                                        # avoid_zero_div branch
+    eps, eps_iter = 2.0, 0.5
+    want = o.pgd_tail_given_grad(x, g, x0, eps_iter, eps, 2, -1, 1)
+    mid = ops.l2_fgm(x.to(DEV), g.to(DEV), eps_iter, -1, 1)
+    got = ops.l2_project(mid, x0.to(DEV), eps, -1, 1)
+    # tolerance: norms agree to 2e-6 relative -> perturbations (|.| <= 2) to ~4e-6 absolute
+    assert torch.allclose(got.cpu(), want, rtol=0, atol=5e-6)
+    assert torch.allclose(mid.cpu(), o.fgm_update_given_grad(x, g, eps_iter, 2, -1, 1), rtol=0, atol=5e-6)
+
+
+def test_l1_fgm_and_utils_tolerance():
+    ops = _ops()
+    from vqattack_amd import utils
+    shape = (3, 3, 6, 5)
+    x = _rand(shape, 20)
+    g = torch.from_numpy(np.random.RandomState(21).standard_normal(shape).astype(np.float32))
+    g[1, 0, 0, 0] = 8.0
+    g[1, 2, 5, 4] = -8.0          # two-way tie
+    want = o.fgm_update_given_grad(x, g, 0.7, 1, -1, 1)
+    assert torch.equal(ops.l1_fgm(x.to(DEV), g.to(DEV), 0.7, -1, 1).cpu(), want)   # exact: max/compare/divide by count
+    assert torch.equal(utils.optimize_linear(g.to(DEV), 1.5, 1).cpu(), o.optimize_linear(g.clone(), 1.5, 1))
+    t = torch.from_numpy(np.random.RandomState(22).standard_normal((6, 3, 5, 4)).astype(np.float32))
+    t[1] = 0
+    t[3] *= 1e-8
+    assert torch.allclose(utils.optimize_linear(t.to(DEV), 0.3, 2).cpu(), o.optimize_linear(t.clone(), 0.3, 2),
+                          rtol=5e-6, atol=1e-12)
+    td = t.to(DEV)
+    r = utils.clip_eta(td, 2, 0.5)
+    assert r.data_ptr() == td.data_ptr()                            # in place, like the reference
+    assert torch.allclose(r.cpu(), o.clip_eta(t.clone(), 2, 0.5), rtol=5e-6, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        utils.clip_eta(td, 1, 0.5)
+    with pytest.raises(ValueError):
+        utils.clip_eta(td, 3, 0.5)
+    with pytest.raises(NotImplementedError):
+        utils.optimize_linear(td, 0.5, 3)
+
+
+# ----------------------------------------------------------------------------- cosine loss
+def _cos_ref(a, b, mask=None):
+    a = a.clone().requires_grad_(True)
+    c = torch.nn.CosineSimilarity(dim=-1, eps=1e-6)(a, b)
+    if mask is not None:
+        c = c * mask
+    loss = torch.sum(-c)
+    loss.backward()
+    return loss.detach(), a.grad
+
+
+@pytest.mark.parametrize("rows0,rows1,d", [(13, 617, 768), (3, 17, 16), (25, 40, 1024), (1, 13, 768), (2, 3, 2048),
+                                          (2, 5, 260)], ids=str)
+def test_neg_cos_rows(rows0, rows1, d):
+    ops = _ops()
+    r = np.random.RandomState(23)
+    a = torch.from_numpy(r.standard_normal((rows0, rows1, d)).astype(np.float32))
+    b = torch.from_numpy(r.standard_normal((rows0, rows1, d)).astype(np.float32))
+    a[0, 0] = 0.0                                # |a| <= eps branch
+    b[0, 1 % rows1] = 0.0
+    want_loss, want_grad = _cos_ref(a, b)
+    slot = torch.zeros(1, device=DEV)
+    ga = ops.neg_cos_rows(a.to(DEV), b.to(DEV), slot, accumulate=False)
+    # tolerance: fp32 dot/norm reductions in a different order than ATen -> 1e-5 relative on the loss,
+    # 1e-5 of the gradient scale (1/|a|) on the gradient
+    assert torch.allclose(slot.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
+    # accumulate + negative scale (targeted)
+    ops.neg_cos_rows(a.to(DEV), b.to(DEV), slot, accumulate=True, gscale=-1.0, want_grad=False)
+    assert abs(float(slot.item())) <= 1e-4 * max(1.0, abs(float(want_loss)))
+
+
+def test_neg_cos_rows_strided_views_2d_and_mask():
+    ops = _ops()
+    r = np.random.RandomState(24)
+    full_a = torch.from_numpy(r.standard_normal((6, 20, 64)).astype(np.float32))
+    full_b = torch.from_numpy(r.standard_normal((6, 23, 64)).astype(np.float32))
+    a, b = full_a[:, :17], full_b[:, :17]                    # the reference's [:, :feat_len, :] truncation
+    want_loss, want_grad = _cos_ref(a.contiguous(), b.contiguous())
+    slot = torch.zeros(1, device=DEV)
+    ga = ops.neg_cos_rows(full_a.to(DEV)[:, :17], full_b.to(DEV)[:, :17], slot, accumulate=False)
+    assert ga.shape == a.shape
+    assert torch.allclose(slot.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
+    a2, b2 = full_a[0], full_b[0, :20]                      # 2-d (rows, D)
+    want_loss, want_grad = _cos_ref(a2, b2)
+    ga = ops.neg_cos_rows(a2.to(DEV), b2.to(DEV), slot, accumulate=False)
+    assert torch.allclose(slot.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
+    # row mask with period 2 over the outer axis (layer-major packing of a batch of 2)
+    mask = torch.from_numpy((r.uniform(size=(2, 20)) > 0.3).astype(np.uint8))
+    a3, b3 = full_a, full_b[:, :20].contiguous()
+    m_full = mask.repeat(3, 1).float()                       # outer index o -> mask row o % 2
+    want_loss, want_grad = _cos_ref(a3, b3, m_full)
+    ga = ops.neg_cos_rows(a3.to(DEV), b3.to(DEV), slot, accumulate=False, row_mask=mask.to(DEV), mask_period=2)
+    assert torch.allclose(slot.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- text side
+def test_gather_rows_exact():
+    ops = _ops()
+    src = torch.from_numpy(np.random.RandomState(25).standard_normal((3, 40, 768)).astype(np.float32))
+    for idx in ([1, 3, 4], [39], [0, 0, 5, -1], []):
+        got = ops.gather_rows(src.to(DEV), idx)
+        assert torch.equal(got.cpu(), src[:, idx])
+    small = src[:, :, :6].contiguous()                        # D not a multiple of 4 -> scalar path
+    assert torch.equal(ops.gather_rows(small.to(DEV), [2, 7]).cpu(), small[:, [2, 7]])
+    with pytest.raises(IndexError):
+        ops.gather_rows(src.to(DEV), [40])
+
+
+@pytest.mark.parametrize("d", [768, 1024, 64])
+def test_cand_dir_sim(d):
+    ops = _ops()
+    from oracle import text_scoring as ts
+    r = np.random.RandomState(26)
+    vocab, length, nb, k = 500, 12, 3, 4
+    f = lambda *s: torch.from_numpy(r.standard_normal(s).astype(np.float32))   # noqa: E731
+    word, pos, typ = f(vocab, d) * 0.05, f(64, d) * 0.05, f(2, d) * 0.05
+    gamma, beta = 1 + 0.1 * f(d), 0.1 * f(d)
+    ids = torch.from_numpy(r.randint(0, vocab, (nb, length)))
+    e_ori = ts.bert_embeddings(ids, word, pos, typ, gamma, beta, 1e-12)
+    grad = f(nb, k, d)
+    cand = torch.tensor([[s, p, kk, v] for s in range(nb) for (p, kk) in ((1, 0), (5, 2), (11, 3))
+                         for v in r.randint(0, vocab, 3)], dtype=torch.int32)
+    want = ts.candidate_scores(ids, e_ori, grad, cand, word, pos, typ, gamma, beta, 1e-12)
+    got = ops.cand_dir_sim(word.to(DEV), pos.to(DEV), typ.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-12,
+                           e_ori.to(DEV), grad.to(DEV), cand.to(DEV))
+    # tolerance: cosine of fp32 LayerNorm outputs, reduction order differs -> 2e-5 absolute on a value in [-1, 1]
+    # (a candidate equal to the original token is never scored: the reference filters it out, adv_attack.py:250-251)
+    assert torch.allclose(got.cpu(), want, rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- BASELINE sizes: properties
+@pytest.mark.parametrize("batch", [64, 256])
+def test_linf_step_full_size_properties(batch):
+    """At BASELINE.json's sizes the CPU oracle is replaced by size-independent properties plus the reference's own
+    eager chain evaluated by PyTorch-ROCm on the device (the op chain the authors ran on their GPU)."""
+    ops = _ops()
+    shape = (batch, 3, 384, 384)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x0 = torch.empty(shape, device=DEV).uniform_(-1, 1, generator=gen)
+    eps, eps_iter = 0.125, 0.01
+    x = torch.clamp(x0 + torch.empty(shape, device=DEV).uniform_(-eps, eps, generator=gen), -1, 1)
+    g = torch.randn(shape, device=DEV, generator=gen)
+    g.view(-1)[::1000] = 0
+    out = ops.linf_step(x, g, x0, eps_iter, eps, -1, 1)
+    # (1) reference chain, eager on the device
+    a = torch.clamp(x + eps_iter * torch.sign(g), -1, 1)
+    ref = torch.clamp(x0 + torch.clamp(a - x0, -eps, eps), -1, 1)
+    assert torch.equal(out, ref)
+    del a, ref
+    # (2) invariants
+    assert float((out - x0).abs().max()) <= np.float32(eps) + 1e-7
+    assert float(out.max()) <= 1 and float(out.min()) >= -1
+    assert float((out - x).abs().max()) <= np.float32(eps_iter) * 1.0001
+    # (3) projection is idempotent on the result; a zero gradient leaves a feasible point unchanged
+    assert torch.equal(ops.linf_project(out, x0, eps, -1, 1), out)
+    assert torch.equal(ops.linf_step(out, torch.zeros_like(g), x0, eps_iter, eps, -1, 1), out)
+    # (4) antisymmetry of the step direction: flipping the gradient flips the move where no clamp is active
+    out_neg = ops.linf_step(x, -g, x0, eps_iter, eps, -1, 1)
+    inner = ((x - x0).abs() < eps - 2 * eps_iter) & (x.abs() < 1 - 2 * eps_iter)
+    # (x + e) - x and x - (x - e) round independently: equal to one ulp of |x| <= 1
+    assert torch.allclose((out - x)[inner], -(out_neg - x)[inner], rtol=0, atol=2e-7)

@@ -1,0 +1,115 @@
+"""ctypes binding of ``lib/libvqattack_hip.so`` (C ABI declared in ``include/vqattack_hip.h``).
+
+PyTorch is used for device memory and streams only: every wrapper takes ``torch.Tensor`` arguments, checks
+that they live on a HIP device in the layout the kernel assumes, and launches on torch's CURRENT stream of
+that device.  There is no CPU path: a missing library, a CPU tensor or a failed launch raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvqattack_hip.so")
+
+VQA_CLIP = 1
+VQA_CHECK_RANGE = 2
+
+_c_float_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_f = ctypes.c_float
+_i = ctypes.c_int
+_u = ctypes.c_uint
+_l = ctypes.c_long
+_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/vqattack_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "vqa_abi_version": (_i, []),
+    "vqa_error_string": (ctypes.c_char_p, [_i]),
+    "vqa_set_option": (_i, [_i, _i]),
+    "vqa_linf_init": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p, _p]),
+    "vqa_linf_fgm": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p, _p]),
+    "vqa_linf_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _u, _p, _p]),
+    "vqa_linf_project": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p]),
+    "vqa_clip_eta_linf": (_i, [_p, _p, _sz, _f, _p]),
+    "vqa_optimize_linear_linf": (_i, [_p, _p, _sz, _f, _p]),
+    "vqa_reduce_ws_bytes": (_sz, [_i, _sz]),
+    "vqa_sumsq_per_sample": (_i, [_p, _p, _p, _i, _sz, _p, _p]),
+    "vqa_absmax_ties_per_sample": (_i, [_p, _p, _p, _i, _sz, _p, _p]),
+    "vqa_l2_fgm": (_i, [_p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p, _p]),
+    "vqa_l2_project": (_i, [_p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p]),
+    "vqa_l1_fgm": (_i, [_p, _p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p, _p]),
+    "vqa_scale_per_sample": (_i, [_p, _p, _p, _p, _i, _sz, _f, _i, _p]),
+    "vqa_neg_cos_partials": (_i, []),
+    "vqa_neg_cos_rows": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p]),
+    "vqa_sum_partials": (_i, [_p, _i, _p, _i, _f, _p]),
+    "vqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the kernel library and type its entry points.  Raises if it is absent (no fallback)."""
+    if not os.path.exists(path):
+        raise HipExtensionError(
+            "HIP kernel library not found at {} -- build it with `python -m vqattack_amd.build` "
+            "(or __graft_entry__.build()); vqattack_amd has no CPU or eager fallback".format(path))
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = load_library()
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().vqa_error_string(code)
+        raise HipExtensionError("{} failed: {} ({})".format(what, msg.decode() if msg else "?", code))
+
+
+def stream_for(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dev_f32(t, name, contiguous=True):
+    """Validate a tensor the kernels will read or write through its raw pointer."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("{} must be a torch.Tensor, got {}".format(name, type(t)))
+    if not t.is_cuda:
+        raise HipExtensionError(
+            "{} lives on '{}': the VQAttack hot path of vqattack_amd runs on an MI355X (HIP) device only; "
+            "there is no CPU fallback".format(name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("{} must be float32, got {}".format(name, t.dtype))
+    if contiguous and not t.is_contiguous():
+        raise ValueError("{} must be contiguous".format(name))
+    return t
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def same_device(*ts):
+    devs = {t.device for t in ts if t is not None}
+    if len(devs) > 1:
+        raise ValueError("tensors are on different devices: {}".format(sorted(map(str, devs))))

@@ -1,0 +1,393 @@
+"""Host side of the PGD hot path: the reference's cleverhans-style operators, re-designed for MI355X.
+
+Same names, argument meaning, return values and error behaviour as the reference's
+``cleverhans.torch.attacks.{fast_gradient_method, projected_gradient_descent}[_vl]`` (ALBEF copy:
+``ALBEF_VQAttack/cleverhans/cleverhans/torch/attacks/*.py``; VLMO copy: ``VLMO_VQAttack/cleverhans/...``);
+``flavor`` selects the copy where the two differ (loss definition and ``y`` slicing of the dual-loss loop).
+The drop-in packages under ``vqattack_amd/dropin/`` bind ``flavor`` and re-export these under the reference's
+module paths.
+
+What is different underneath (and invisible to a caller):
+  * the frozen white-box forward/backward is PyTorch-ROCm (``model_fn`` is the caller's), everything between two
+    model calls is ONE hand-written HIP kernel launch (``ops.linf_step``: sign + step + clamp + eps-ball projection +
+    clamp, 16 B/element instead of the reference's 92 B/element eager chain);
+  * the cross-modal cosine loss and its gradient w.r.t. the model outputs come from one fused pass
+    (``ops.neg_cos_rows``) and are handed to autograd as ``grad_tensors`` -- no autograd graph for the loss;
+  * no per-step host sync: losses are written into a device buffer and fetched once when the loop ends (the
+    reference does ``float(loss.cpu())`` every step, projected_gradient_descent.py:145); range-sanity flags are
+    OR-ed into a device word by the kernels and read once;
+  * the input is never cloned (the reference's ``x.clone()`` per step, fast_gradient_method.py:97): the loop owns
+    two ping-pong image buffers.
+There is no CPU path: CPU tensors raise ``HipExtensionError``.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._hip import HipExtensionError, dev_f32
+
+ALBEF = "albef"
+VLMO = "vlmo"
+MLM_VOCAB = 30522   # literal in the reference (fast_gradient_method.py:103)
+
+
+# ----------------------------------------------------------------------------------------- validation
+def _check_flavor(flavor):
+    if flavor not in (ALBEF, VLMO):
+        raise ValueError("flavor must be 'albef' or 'vlmo', got {!r}".format(flavor))
+
+
+def _validate_fgm(norm, eps, clip_min, clip_max):
+    if norm not in (np.inf, 1, 2):
+        raise ValueError("Norm order must be either np.inf, 1, or 2, got {} instead.".format(norm))
+    if eps < 0:
+        raise ValueError("eps must be greater than or equal to 0, got {} instead".format(eps))
+    if clip_min is not None and clip_max is not None and clip_min > clip_max:
+        raise ValueError("clip_min must be less than or equal to clip_max, got clip_min={} and clip_max={}".format(
+            clip_min, clip_max))
+
+
+def _validate_pgd(norm, eps, eps_iter, clip_min, clip_max):
+    """True -> hand the input back unchanged (the reference returns the bare tensor for eps/eps_iter == 0)."""
+    if norm == 1:
+        raise NotImplementedError("PGD with norm=1 is not enabled: norm=1 FGM changes only one pixel at a time "
+                                  "(projected_gradient_descent.py:58-65 of the reference).")
+    if norm not in (np.inf, 2):
+        raise ValueError("Norm order must be either np.inf or 2.")
+    if eps < 0:
+        raise ValueError("eps must be greater than or equal to 0, got {} instead".format(eps))
+    if eps == 0:
+        return True
+    if eps_iter < 0:
+        raise ValueError("eps_iter must be greater than or equal to 0, got {} instead".format(eps_iter))
+    if eps_iter == 0:
+        return True
+    assert eps_iter <= eps, (eps_iter, eps)
+    if clip_min is not None and clip_max is not None and clip_min > clip_max:
+        raise ValueError("clip_min must be less than or equal to clip_max, got clip_min={} and clip_max={}".format(
+            clip_min, clip_max))
+    return False
+
+
+def _two_sided(clip_min, clip_max):
+    if (clip_min is not None or clip_max is not None) and (clip_min is None or clip_max is None):
+        raise ValueError("One of clip_min and clip_max is None but we don't currently support one-sided clipping")
+
+
+def _as_image(x, name="x"):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError("{} must be a torch.Tensor".format(name))
+    if not x.is_cuda:
+        raise HipExtensionError("{} is on '{}': vqattack_amd runs this path on an MI355X HIP device only "
+                                "(no CPU fallback)".format(name, x.device))
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)          # reference: .to(torch.float), fast_gradient_method.py:97
+    return x.contiguous()
+
+
+# ----------------------------------------------------------------------------------------- losses
+class _LossSlot:
+    """One fp32 word of the attack's device-side loss buffer."""
+
+    def __init__(self, buf, index):
+        self.word = buf[index:index + 1]
+
+    def scalar(self):
+        return self.word[0]
+
+
+def _feature_pairs(out, y, flavor, vl):
+    """(model output, target) row-tensor pairs of the feature loss, after the reference's in-place truncation of
+    both LISTS to the common token length (A: fast_gradient_method.py:121-126; V: :107-110)."""
+    if flavor == ALBEF:
+        n1 = min(out[1].shape[1], y[1].shape[1])
+        out[1] = out[1][:, :n1, :]
+        y[1] = y[1][:, :n1, :]
+        n0 = min(out[0].shape[1], y[0].shape[1])
+        out[0] = out[0][:, :n0, :]
+        y[0] = y[0][:, :n0, :]
+        return [(out[1], y[1]), (out[0], y[0])]
+    if vl or out[2].shape[1] != y[2].shape[1]:
+        n = min(out[2].shape[1], y[2].shape[1])
+        out[2] = out[2][:, :n, :]
+        y[2] = y[2][:, :n, :]
+    return [(out[1], y[1]), (out[2], y[2])]
+
+
+def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra_loss=None):
+    """Fused loss + gradient: one HIP pass per pair, then autograd through the model only.
+
+    loss = sign * (extra_scale * sum_pairs sum_rows -cos + extra_loss).  ``extra_loss`` is an optional autograd
+    scalar (the CE terms of the VLMO mixed loss) that is back-propagated in the same autograd sweep.
+    """
+    tensors, grads = [], []
+    gscale = sign * extra_scale
+    for k, (o, t) in enumerate(pairs):
+        if not o.is_cuda or not t.is_cuda:
+            raise HipExtensionError("model_fn outputs and targets y must be on the HIP device")
+        o32 = o if o.dtype == torch.float32 else o.to(torch.float32)
+        t32 = t.detach() if t.dtype == torch.float32 else t.detach().to(torch.float32)
+        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=True)
+        tensors.append(o32)
+        grads.append(ga)
+    if extra_loss is not None:
+        slot.word.add_(extra_loss.detach().to(torch.float32) * sign)
+        tensors.append(extra_loss)
+        grads.append(torch.full_like(extra_loss, float(sign)))
+    torch.autograd.backward(tensors, grads, inputs=leaves)
+
+
+def _mlm_ce(logits, labels):
+    """CE over the MLM vocabulary; 2-d labels or the sum over K label sets of 3-d labels (B, K, L).
+    A: fast_gradient_method.py:131-142; V: :116-126.  (`reshape` where the reference's `view` would reject a
+    non-contiguous slice for batch > 1.)"""
+    flat = logits.reshape(-1, MLM_VOCAB)
+    if labels.dim() == 2:
+        return F.cross_entropy(flat, labels.reshape(-1), ignore_index=-100)
+    if labels.dim() == 3:
+        loss = F.cross_entropy(flat, labels[:, 0, :].reshape(-1), ignore_index=-100)
+        for k in range(1, labels.size(1)):
+            loss = loss + F.cross_entropy(flat, labels[:, k, :].reshape(-1), ignore_index=-100)
+        return loss
+    raise ValueError("MLM labels must be 2-d or 3-d")
+
+
+def _ce_backward(loss, slot, leaves, sign):
+    slot.word.copy_(loss.detach().to(torch.float32).reshape(1) * sign)
+    torch.autograd.backward([loss], [torch.full_like(loss, float(sign))], inputs=leaves)
+
+
+def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bkp=None, bkp_y=None, vl=False):
+    """Run the white box, evaluate the selected loss into ``slot`` and leave d loss/d leaf in ``leaf.grad``."""
+    sign = -1.0 if targeted else 1.0
+    with torch.enable_grad():
+        out = model_fn(model_in)
+        if vl:
+            pairs = _feature_pairs(out, y, flavor, vl=True)     # truncation happens before the `ls` switch
+            if ls == 1:
+                _feature_loss_backward(pairs, slot, leaves, sign)
+            elif ls == 0:
+                _ce_backward(F.cross_entropy(out[0].reshape(-1, MLM_VOCAB), y[0].reshape(-1), ignore_index=-100),
+                             slot, leaves, sign)
+            else:
+                raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
+            return
+        if flavor == ALBEF and ls == 0:
+            # label/logit length mismatch -> feature loss on the backup model (fast_gradient_method.py:102-118)
+            rows = out[0].reshape(-1, MLM_VOCAB).shape[0]
+            lab = y[0]
+            if lab.dim() == 2:
+                bad = lab.reshape(-1).shape[0] != rows
+            elif lab.dim() == 3:
+                bad = any(lab[:, k, :].reshape(-1).shape[0] != rows for k in range(lab.shape[1]))
+            else:
+                bad = False
+            if bad:
+                ls, out, y = 1, bkp(model_in), bkp_y
+        if ls == 1:
+            _feature_loss_backward(_feature_pairs(out, y, flavor, vl=False), slot, leaves, sign)
+        elif ls == 0:
+            _ce_backward(_mlm_ce(out[0], y[0]), slot, leaves, sign)
+        elif flavor == VLMO:
+            # mixed loss, V: fast_gradient_method.py:127-131 (no truncation in this branch)
+            flat = out[0].reshape(-1, MLM_VOCAB)
+            ce = 0.1 * F.cross_entropy(flat, y[0].reshape(-1), ignore_index=-100)
+            for syn in y[3]:
+                ce = ce + 0.1 * F.cross_entropy(flat, syn[0].reshape(-1), ignore_index=-100)
+            scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
+            _feature_loss_backward([(out[1], y[1]), (out[2], y[2])], slot, leaves, sign, extra_scale=scale,
+                                   extra_loss=ce)
+        else:
+            raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
+
+
+# ----------------------------------------------------------------------------------------- image updates
+def _fgm_update(x, grad, eps, norm, clip_min, clip_max, flag=None, out=None):
+    if norm == np.inf:
+        return ops.linf_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
+    if norm == 2:
+        return ops.l2_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
+    return ops.l1_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
+
+
+def _fgm_then_project(x, grad, x0, eps_iter, eps, norm, clip_min, clip_max, out):
+    if norm == np.inf:
+        return ops.linf_step(x, grad, x0, eps_iter, eps, clip_min, clip_max, out=out)
+    mid = ops.l2_fgm(x, grad, eps_iter, clip_min, clip_max)
+    return ops.l2_project(mid, x0, eps, clip_min, clip_max, out=out)
+
+
+def _grad_of(leaf):
+    g = leaf.grad
+    if g is None:
+        raise RuntimeError("model_fn's output does not depend on the image: no gradient reached x")
+    return g if g.is_contiguous() else g.contiguous()
+
+
+# ----------------------------------------------------------------------------------------- FGM
+def fast_gradient_method(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=None, y=None, targeted=False,
+                         sanity_checks=False, ls=None, bkp=None, bkp_y=None, *, flavor=ALBEF):
+    """One FGM step; returns ``(adv_x, loss)`` (``loss`` is a 0-d device tensor), bare ``x`` when ``eps == 0``.
+    Reference: A fast_gradient_method.py:30-165, V :36-152 (the VLMO copy has no ``bkp``/``bkp_y``)."""
+    _check_flavor(flavor)
+    _validate_fgm(norm, eps, clip_min, clip_max)
+    if eps == 0:
+        return x
+    xin = _as_image(x)
+    flag = ops.new_flag(xin.device) if (sanity_checks and (clip_min is not None or clip_max is not None)) else None
+    leaf = xin.detach().requires_grad_(True)           # shares storage with x: nothing is written in place
+    loss_buf = torch.zeros(1, dtype=torch.float32, device=xin.device)
+    _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, 0), bkp=bkp, bkp_y=bkp_y)
+    _two_sided(clip_min, clip_max)
+    adv = _fgm_update(xin, _grad_of(leaf), eps, norm, clip_min, clip_max, flag=flag)
+    if sanity_checks and flag is not None:
+        assert int(flag.item()) == 0, "input x is outside [clip_min, clip_max]"
+    return adv, loss_buf[0]
+
+
+def fast_gradient_method_vl(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=None, y=None, targeted=False,
+                            sanity_checks=False, ls=None, text_emb_pick=None, *, flavor=ALBEF):
+    """FGM on ``x = [image, text_embeds]``; returns ``(adv_image, text_grad[:, text_emb_pick])``.
+    Like the reference it replaces ``x[0]``/``x[1]`` of the caller's list by the leaf tensors.
+    Reference: A fast_gradient_method_vl.py:30-130, V :34-141."""
+    _check_flavor(flavor)
+    _validate_fgm(norm, eps, clip_min, clip_max)
+    if eps == 0:
+        return x
+    img = _as_image(x[0], "x[0]")
+    emb = _as_image(x[1], "x[1]")
+    flag = ops.new_flag(img.device) if (sanity_checks and (clip_min is not None or clip_max is not None)) else None
+    x[0] = img.detach().requires_grad_(True)
+    x[1] = emb.detach().requires_grad_(True)
+    loss_buf = torch.zeros(1, dtype=torch.float32, device=img.device)
+    _loss_and_grad(model_fn, [x[0], x[1]], [x[0], x[1]], y, ls, flavor, targeted, _LossSlot(loss_buf, 0), vl=True)
+    text_grad = ops.gather_rows(_grad_of(x[1]), text_emb_pick)
+    _two_sided(clip_min, clip_max)
+    adv = _fgm_update(img, _grad_of(x[0]), eps, norm, clip_min, clip_max, flag=flag)
+    if sanity_checks and flag is not None:
+        assert int(flag.item()) == 0, "input x is outside [clip_min, clip_max]"
+    return adv, text_grad
+
+
+# ----------------------------------------------------------------------------------------- PGD
+def _start_point(x, norm, eps, clip_min, clip_max, time, rand_minmax, init_eta, flag, out):
+    """adv_0 = clamp(x + clip_eta(eta)) with eta = U(-r, r) iff ``time == 0`` (the reference derives rand_init from
+    ``time`` and ignores the kwarg: projected_gradient_descent.py:106-120)."""
+    eta = None
+    if time == 0:
+        if init_eta is not None:
+            eta = _as_image(init_eta, "init_eta")
+            if eta.shape != x.shape:
+                raise ValueError("init_eta shape {} != x shape {}".format(tuple(eta.shape), tuple(x.shape)))
+        else:
+            r = eps if rand_minmax is None else rand_minmax
+            eta = torch.empty_like(x).uniform_(-r, r)
+        if norm == 2:
+            eta = ops.scale_per_sample(eta, ops.sumsq_per_sample(eta), None, eps, kind=0)
+    bound = eps if norm == np.inf else float("inf")
+    return ops.linf_init(x, eta, bound, clip_min, clip_max, flag=flag, out=out)
+
+
+def _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks):
+    ok = [eps_iter <= eps]
+    if norm == np.inf and clip_min is not None:
+        ok.append(eps + clip_min <= clip_max)
+    if sanity_checks:
+        if flag is not None:
+            ok.append(int(flag.item()) == 0)     # the only host read of the flag word
+        assert np.all(ok)
+
+
+def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_min=None, clip_max=None, y=None,
+                               ori_x=None, time=None, targeted=False, rand_init=True, rand_minmax=None,
+                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None):
+    """PGD over a frozen white box; returns ``(adv_x, loss_list)``, bare ``x`` when eps or eps_iter is 0.
+
+    ``ls == 1``: feature loss, ``model_fn`` a callable.  Otherwise the dual-loss loop: ``model_fn = [feature_fn,
+    mlm_fn]``, one feature step then one MLM step per iteration with a single projection after both.
+    ``init_eta`` (extension, keyword-only): the uniform draw to use when ``time == 0`` (for reproducible parity runs).
+    Reference: A projected_gradient_descent.py:10-199, V :10-196.
+    """
+    _check_flavor(flavor)
+    if _validate_pgd(norm, eps, eps_iter, clip_min, clip_max):
+        return x
+    xin = _as_image(x)
+    has_clip = clip_min is not None or clip_max is not None
+    flag = ops.new_flag(xin.device) if has_clip else None
+    buf = [torch.empty_like(xin), torch.empty_like(xin)]
+    adv = _start_point(xin, norm, eps, clip_min, clip_max, time, rand_minmax, init_eta, flag, buf[0])
+    cur = 0
+    if y is None:
+        _, y = torch.max(model_fn(xin), 1)   # kept for API parity; every VQAttack caller passes y
+    x0 = _as_image(ori_x, "ori_x")
+    if x0.shape != xin.shape:
+        raise ValueError("ori_x shape {} != x shape {}".format(tuple(x0.shape), tuple(xin.shape)))
+    dual = ls != 1
+    loss_buf = torch.zeros(max(nb_iter, 1) * (2 if dual else 1), dtype=torch.float32, device=xin.device)
+    n_loss = 0
+    for _ in range(nb_iter):
+        if not dual:
+            leaf = adv.detach().requires_grad_(True)
+            _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, n_loss))
+            n_loss += 1
+            _two_sided(clip_min, clip_max)
+            adv = _fgm_then_project(adv, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])
+        else:
+            if flavor == ALBEF:      # A :163,177-181 slices y; V :162,175 passes it whole
+                y_feat, y_mlm, extra = [y[1], y[2]], [y[0]], dict(bkp=model_fn[0], bkp_y=[y[1], y[2]])
+            else:
+                y_feat, y_mlm, extra = y, y, {}
+            leaf = adv.detach().requires_grad_(True)
+            _loss_and_grad(model_fn[0], [leaf], leaf, y_feat, 1, flavor, targeted, _LossSlot(loss_buf, n_loss))
+            n_loss += 1
+            _two_sided(clip_min, clip_max)
+            mid = _fgm_update(adv, _grad_of(leaf), eps_iter, norm, clip_min, clip_max, out=buf[1 - cur])
+            leaf = mid.detach().requires_grad_(True)
+            _loss_and_grad(model_fn[1], [leaf], leaf, y_mlm, 0, flavor, targeted, _LossSlot(loss_buf, n_loss), **extra)
+            n_loss += 1
+            adv = _fgm_then_project(mid, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[cur])
+            cur = 1 - cur            # result sits in buf[cur] again after the flip below
+        cur = 1 - cur
+        del leaf
+    _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)
+    loss_list = loss_buf[:n_loss].tolist()     # single device->host transfer for the whole loop
+    return adv, loss_list
+
+
+def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, clip_min=None, clip_max=None, y=None,
+                                  ori_x=None, time=None, targeted=False, rand_init=True, rand_minmax=None,
+                                  sanity_checks=True, ls=None, attack_mask=None, *, flavor=ALBEF, init_eta=None):
+    """PGD on ``x = [image, text_embeds]`` (only the image moves); returns ``(adv_image, text_embed_gradient)`` of
+    the last iteration.  Only ``ls == 1`` is supported (``ValueError`` otherwise), as in the reference.
+    Reference: A projected_gradient_descent_vl.py:10-168, V :10-164."""
+    _check_flavor(flavor)
+    if _validate_pgd(norm, eps, eps_iter, clip_min, clip_max):
+        return x
+    img = _as_image(x[0], "x[0]")
+    emb = _as_image(x[1], "x[1]")
+    has_clip = clip_min is not None or clip_max is not None
+    flag = ops.new_flag(img.device) if has_clip else None
+    buf = [torch.empty_like(img), torch.empty_like(img)]
+    adv = _start_point(img, norm, eps, clip_min, clip_max, time, rand_minmax, init_eta, flag, buf[0])
+    cur = 0
+    if y is None:
+        _, y = torch.max(model_fn(x), 1)
+    x0 = _as_image(ori_x, "ori_x")
+    if ls != 1:
+        raise ValueError("projected_gradient_descent_vl supports ls == 1 only")
+    text_grad = None
+    loss_buf = torch.zeros(max(nb_iter, 1), dtype=torch.float32, device=img.device)
+    for it in range(nb_iter):
+        leaf_img = adv.detach().requires_grad_(True)
+        leaf_txt = emb.detach().requires_grad_(True)
+        _loss_and_grad(model_fn, [leaf_img, leaf_txt], [leaf_img, leaf_txt], y, ls, flavor, targeted,
+                       _LossSlot(loss_buf, it), vl=True)
+        text_grad = ops.gather_rows(_grad_of(leaf_txt), attack_mask)
+        _two_sided(clip_min, clip_max)
+        adv = _fgm_then_project(adv, _grad_of(leaf_img), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])
+        cur = 1 - cur
+        del leaf_img, leaf_txt
+    _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)
+    return adv, text_grad

@@ -1,0 +1,54 @@
+"""Build the gfx950 kernels into ``vqattack_amd/lib/libvqattack_hip.so`` (C ABI: include/vqattack_hip.h).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so travels to the GPU
+box with the tree (it is git-ignored, not gpurun-ignored).  ``python -m vqattack_amd.build [--force]``.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC_DIR = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip.so")
+SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "text.hip"]
+# -ffp-contract=off: the reference's op chain rounds after every add/mul; keep it that way (bit-exact parity).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP kernels of vqattack_amd cannot be built")
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)]
+    deps.append(os.path.join(HERE, "..", "include", "vqattack_hip.h"))
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + FLAGS + [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    if verbose and proc.stderr.strip():
+        print(proc.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

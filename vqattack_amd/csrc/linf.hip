@@ -1,0 +1,224 @@
+// L-infinity image-update kernels of the PGD loop (gfx950 / MI355X).
+//
+// All kernels here are pure HBM streams (arithmetic intensity < 0.5 flop/B): one 16-byte load per lane per
+// stream, U tiles in flight per wave before the first use, 256-thread workgroups, a grid capped at
+// 8 workgroups per CU that grid-strides over block-contiguous tiles.  No LDS, no MFMA: there is no reuse to
+// stage and no contraction.  The arithmetic is the reference's op chain in its exact fp32 order (see
+// include/vqattack_hip.h), compiled with -ffp-contract=off, so results are bit-identical to eager PyTorch.
+#include "common.hpp"
+
+namespace vqa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- tuning knobs (vqa_set_option), defaults chosen from the round-1 sweep recorded in DESIGN.md
+static int g_opt_blocks_per_cu = 8;   // option 0
+static int g_opt_nontemporal = 1;     // option 1: bit0 = nt loads of g, bit1 = nt stores of out
+
+struct StepParams {
+  float eps_iter, eps, cmin, cmax;
+  unsigned mode;
+};
+
+// ---- per-element bodies -----------------------------------------------------------------------
+struct InitOp {   // out = clamp(x + clamp(eta, +-eps))
+  static constexpr int kIn = 2;
+  __device__ static float apply(const StepParams& p, float x, float eta, float, bool& bad) {
+    if (p.mode & VQA_CHECK_RANGE) bad |= out_of_range(x, p.cmin, p.cmax);
+    float v = x + clamp_torch(eta, -p.eps, p.eps);
+    return (p.mode & VQA_CLIP) ? clamp_torch(v, p.cmin, p.cmax) : v;
+  }
+};
+struct InitZeroOp {   // eta == 0: out = clamp(x + 0)
+  static constexpr int kIn = 1;
+  __device__ static float apply(const StepParams& p, float x, float, float, bool& bad) {
+    if (p.mode & VQA_CHECK_RANGE) bad |= out_of_range(x, p.cmin, p.cmax);
+    float v = x + 0.0f;
+    return (p.mode & VQA_CLIP) ? clamp_torch(v, p.cmin, p.cmax) : v;
+  }
+};
+struct FgmOp {   // out = clamp(x + eps_iter * sign(g))
+  static constexpr int kIn = 2;
+  __device__ static float apply(const StepParams& p, float x, float g, float, bool& bad) {
+    if (p.mode & VQA_CHECK_RANGE) bad |= out_of_range(x, p.cmin, p.cmax);
+    float v = x + p.eps_iter * sign_torch(g);
+    return (p.mode & VQA_CLIP) ? clamp_torch(v, p.cmin, p.cmax) : v;
+  }
+};
+struct StepOp {   // FGM update + projection on the eps-ball around x0
+  static constexpr int kIn = 3;
+  __device__ static float apply(const StepParams& p, float x, float g, float x0, bool& bad) {
+    if (p.mode & VQA_CHECK_RANGE) bad |= out_of_range(x, p.cmin, p.cmax);
+    float a = x + p.eps_iter * sign_torch(g);
+    if (p.mode & VQA_CLIP) a = clamp_torch(a, p.cmin, p.cmax);
+    float e = clamp_torch(a - x0, -p.eps, p.eps);
+    float v = x0 + e;
+    return (p.mode & VQA_CLIP) ? clamp_torch(v, p.cmin, p.cmax) : v;
+  }
+};
+struct ProjectOp {   // out = clamp(x0 + clamp(adv - x0, +-eps)); stream 0 = adv, stream 1 = x0
+  static constexpr int kIn = 2;
+  __device__ static float apply(const StepParams& p, float adv, float x0, float, bool&) {
+    float e = clamp_torch(adv - x0, -p.eps, p.eps);
+    float v = x0 + e;
+    return (p.mode & VQA_CLIP) ? clamp_torch(v, p.cmin, p.cmax) : v;
+  }
+};
+struct ClipEtaOp {
+  static constexpr int kIn = 1;
+  __device__ static float apply(const StepParams& p, float eta, float, float, bool&) {
+    return clamp_torch(eta, -p.eps, p.eps);
+  }
+};
+struct SignScaleOp {
+  static constexpr int kIn = 1;
+  __device__ static float apply(const StepParams& p, float g, float, float, bool&) {
+    return p.eps * sign_torch(g);
+  }
+};
+
+// ---- 16-byte streaming kernel -----------------------------------------------------------------
+// NT bit0: the second stream (the gradient, read exactly once) is loaded non-temporally;
+// NT bit1: the result is stored non-temporally.
+template <class Op, int U, int NT>
+__global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // may alias out (in-place update)
+                                                         const f32x4* __restrict__ s1,
+                                                         const f32x4* __restrict__ s2,
+                                                         f32x4* out, size_t n4,
+                                                         StepParams p, int* __restrict__ flag) {
+  const size_t tile = static_cast<size_t>(kBlock) * U;
+  const size_t stride = static_cast<size_t>(gridDim.x) * tile;
+  bool bad = false;
+  for (size_t base = static_cast<size_t>(blockIdx.x) * tile; base < n4; base += stride) {
+    f32x4 v0[U], v1[U], v2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+      if (i < n4) {
+        v0[u] = s0[i];
+        if (Op::kIn > 1) v1[u] = (NT & 1) ? __builtin_nontemporal_load(&s1[i]) : s1[i];
+        if (Op::kIn > 2) v2[u] = s2[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+      if (i < n4) {
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          r[k] = Op::apply(p, v0[u][k], Op::kIn > 1 ? v1[u][k] : 0.0f, Op::kIn > 2 ? v2[u][k] : 0.0f, bad);
+        if (NT & 2)
+          __builtin_nontemporal_store(r, &out[i]);
+        else
+          out[i] = r;
+      }
+    }
+  }
+  if ((p.mode & VQA_CHECK_RANGE) && bad) atomicOr(flag, 1);
+}
+
+// scalar path: unaligned buffers and the <= 3 element tail
+template <class Op>
+__global__ __launch_bounds__(kBlock) void stream1_kernel(const float* s0,
+                                                         const float* __restrict__ s1,
+                                                         const float* __restrict__ s2,
+                                                         float* out, size_t begin, size_t n,
+                                                         StepParams p, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = begin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * kBlock) {
+    out[i] = Op::apply(p, s0[i], Op::kIn > 1 ? s1[i] : 0.0f, Op::kIn > 2 ? s2[i] : 0.0f, bad);
+  }
+  if ((p.mode & VQA_CHECK_RANGE) && bad) atomicOr(flag, 1);
+}
+
+template <class Op, int U>
+static int launch_stream(const float* s0, const float* s1, const float* s2, float* out, size_t n,
+                         const StepParams& p, int* flag, vqa_stream_t stream) {
+  if (!s0 || !out || (Op::kIn > 1 && !s1) || (Op::kIn > 2 && !s2)) return VQA_ERR_NULL;
+  if ((p.mode & VQA_CHECK_RANGE) && !flag) return VQA_ERR_NULL;
+  if (!aligned4(s0) || !aligned4(out) || (s1 && !aligned4(s1)) || (s2 && !aligned4(s2))) return VQA_ERR_ALIGN;
+  if (n == 0) return VQA_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = aligned16(s0) && aligned16(out) && (Op::kIn < 2 || aligned16(s1)) &&
+                   (Op::kIn < 3 || aligned16(s2));
+  size_t done = 0;
+  if (vec && n >= 4) {
+    const size_t n4 = n / 4;
+    const int grid = blocks_for(n4, kBlock * U, 256 * g_opt_blocks_per_cu);
+    auto a0 = reinterpret_cast<const f32x4*>(s0);
+    auto a1 = reinterpret_cast<const f32x4*>(s1);
+    auto a2 = reinterpret_cast<const f32x4*>(s2);
+    auto o = reinterpret_cast<f32x4*>(out);
+    switch (g_opt_nontemporal & 3) {
+      case 0: stream4_kernel<Op, U, 0><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
+      case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
+      case 2: stream4_kernel<Op, U, 2><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
+      default: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
+    }
+    done = n4 * 4;
+  }
+  if (done < n) {
+    const int grid = blocks_for(n - done, kBlock);
+    stream1_kernel<Op><<<grid, kBlock, 0, st>>>(s0, s1, s2, out, done, n, p, flag);
+  }
+  return launch_status();
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" {
+
+int vqa_set_option(int option, int value) {
+  switch (option) {
+    case 0:
+      if (value < 1 || value > 64) return VQA_ERR_SHAPE;
+      g_opt_blocks_per_cu = value;
+      return VQA_OK;
+    case 1:
+      g_opt_nontemporal = value & 3;
+      return VQA_OK;
+    default:
+      return VQA_ERR_SHAPE;
+  }
+}
+
+int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float eps, float cmin, float cmax,
+                  unsigned mode, int* flag, vqa_stream_t stream) {
+  StepParams p{0.0f, eps, cmin, cmax, mode};
+  if (eta) return launch_stream<InitOp, 4>(x, eta, nullptr, out, n, p, flag, stream);
+  return launch_stream<InitZeroOp, 4>(x, nullptr, nullptr, out, n, p, flag, stream);
+}
+
+int vqa_linf_fgm(const float* x, const float* g, float* out, size_t n, float eps_iter, float cmin, float cmax,
+                 unsigned mode, int* flag, vqa_stream_t stream) {
+  StepParams p{eps_iter, 0.0f, cmin, cmax, mode};
+  return launch_stream<FgmOp, 4>(x, g, nullptr, out, n, p, flag, stream);
+}
+
+int vqa_linf_step(const float* x, const float* g, const float* x0, float* out, size_t n, float eps_iter,
+                  float eps, float cmin, float cmax, unsigned mode, int* flag, vqa_stream_t stream) {
+  StepParams p{eps_iter, eps, cmin, cmax, mode};
+  return launch_stream<StepOp, 4>(x, g, x0, out, n, p, flag, stream);
+}
+
+int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, float eps, float cmin,
+                     float cmax, unsigned mode, vqa_stream_t stream) {
+  StepParams p{0.0f, eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
+  return launch_stream<ProjectOp, 4>(adv, x0, nullptr, out, n, p, nullptr, stream);
+}
+
+int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream) {
+  StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
+  return launch_stream<ClipEtaOp, 4>(eta, nullptr, nullptr, out, n, p, nullptr, stream);
+}
+
+int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream) {
+  StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
+  return launch_stream<SignScaleOp, 4>(g, nullptr, nullptr, out, n, p, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Text side of the joint attack: gather of text-embedding gradient rows and candidate-substitution scoring
+// (gfx950 / MI355X).  Both are row-granular HBM/L2 gathers: one wavefront per row, 16-byte lanes, the row held
+// in registers (D <= 2048), wave-shuffle reductions -- no LDS, no atomics.
+#include "common.hpp"
+
+namespace vqa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxCh = 8;   // 8 x 256 floats = D <= 2048
+
+// dst[b, k, :] = src[b, idx[k], :]
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ src,
+                                                             const int64_t* __restrict__ idx,
+                                                             float* __restrict__ dst, int B, int L, int K, int D,
+                                                             int vec) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long rows = static_cast<long>(B) * K;
+  for (long r = static_cast<long>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave; r < rows;
+       r += static_cast<long>(gridDim.x) * kWavesPerBlock) {
+    const long b = r / K, k = r - b * K;
+    long t = idx[k];
+    if (t < 0) t += L;                       // python-style negative index
+    if (t < 0 || t >= L) continue;           // host validates; never read out of bounds
+    const float* s = src + (b * L + t) * D;
+    float* d = dst + r * D;
+    if (vec) {
+      for (int c = lane * 4; c < D; c += kWave * 4)
+        *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
+    } else {
+      for (int c = lane; c < D; c += kWave) d[c] = s[c];
+    }
+  }
+}
+
+// One wave per candidate {sample, position, grad row, vocab id}.
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void cand_dir_sim_kernel(
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float ln_eps,
+    const float* __restrict__ e_ori, const float* __restrict__ grad, const int32_t* __restrict__ cand,
+    float* __restrict__ out, int n_cand, int L, int K, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int c = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave; c < n_cand; c += gridDim.x * kWavesPerBlock) {
+    const int s = cand[4 * c + 0], p = cand[4 * c + 1], k = cand[4 * c + 2], v = cand[4 * c + 3];
+    const float* pw = word + static_cast<long>(v) * D;
+    const float* pp = pos + static_cast<long>(p) * D;
+    const float* po = e_ori + (static_cast<long>(s) * L + p) * D;
+    const float* pg = grad + (static_cast<long>(s) * K + k) * D;
+    f32x4 e[NCH];
+    float sum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+        f32x4 w = *reinterpret_cast<const f32x4*>(pw + d);
+        f32x4 q = *reinterpret_cast<const f32x4*>(pp + d);
+        f32x4 t = *reinterpret_cast<const f32x4*>(type + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[ch][j] = (w[j] + t[j]) + q[j];   // BertEmbeddings: inputs_embeds + token_type, then + position
+          sum += e[ch][j];
+        }
+      } else {
+        e[ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+    const float mean = wave_sum(sum) / static_cast<float>(D);
+    float var = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c0 = e[ch][j] - mean;
+          var += c0 * c0;
+        }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / static_cast<float>(D) + ln_eps);
+    float dd = 0.0f, gg = 0.0f, dg = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+        f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + d);
+        f32x4 be = *reinterpret_cast<const f32x4*>(beta + d);
+        f32x4 eo = *reinterpret_cast<const f32x4*>(po + d);
+        f32x4 gr = *reinterpret_cast<const f32x4*>(pg + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ln = (e[ch][j] - mean) * rstd * ga[j] + be[j];
+          const float dir = ln - eo[j];
+          dd += dir * dir;
+          gg += gr[j] * gr[j];
+          dg += dir * gr[j];
+        }
+      }
+    }
+    dd = wave_sum(dd);
+    gg = wave_sum(gg);
+    dg = wave_sum(dg);
+    // F.normalize(p=2, eps=1e-12) on both vectors, then CosineSimilarity(eps=1e-6) of the unit vectors
+    const float nd = fmaxf(sqrtf(dd), 1e-12f), ng = fmaxf(sqrtf(gg), 1e-12f);
+    const float und = sqrtf(dd) / nd, ung = sqrtf(gg) / ng;       // norms of the normalised vectors (1 or 0)
+    const float cosv = (dg / (nd * ng)) / (fmaxf(und, 1e-6f) * fmaxf(ung, 1e-6f));
+    if (lane == 0) out[c] = cosv;
+  }
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" {
+
+int vqa_gather_rows(const float* src, const int64_t* idx, float* dst, int B, int L, int K, int D,
+                    vqa_stream_t stream) {
+  if (!src || !idx || !dst) return VQA_ERR_NULL;
+  if (B < 0 || L <= 0 || K < 0 || D <= 0) return VQA_ERR_SHAPE;
+  if (!aligned4(src) || !aligned4(dst)) return VQA_ERR_ALIGN;
+  if (B == 0 || K == 0) return VQA_OK;
+  const int vec = (D % 4 == 0) && aligned16(src) && aligned16(dst);
+  const int grid = blocks_for(static_cast<size_t>(B) * K, kWavesPerBlock);
+  gather_rows_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(src, idx, dst, B, L, K, D, vec);
+  return launch_status();
+}
+
+int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                     float ln_eps, const float* e_ori, const float* grad, const int32_t* cand, float* out,
+                     int n_cand, int L, int K, int D, vqa_stream_t stream) {
+  if (!word || !pos || !type || !gamma || !beta || !e_ori || !grad || !cand || !out) return VQA_ERR_NULL;
+  if (n_cand < 0 || L <= 0 || K <= 0 || D <= 0 || D > 256 * kMaxCh || (D & 3)) return VQA_ERR_SHAPE;
+  if (!aligned16(word) || !aligned16(pos) || !aligned16(type) || !aligned16(gamma) || !aligned16(beta) ||
+      !aligned16(e_ori) || !aligned16(grad))
+    return VQA_ERR_ALIGN;
+  if (n_cand == 0) return VQA_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = blocks_for(static_cast<size_t>(n_cand), kWavesPerBlock);
+#define VQA_CAND(N) \
+  cand_dir_sim_kernel<N><<<grid, kBlock, 0, st>>>(word, pos, type, gamma, beta, ln_eps, e_ori, grad, cand, out, \
+                                                  n_cand, L, K, D)
+  switch ((D + 255) / 256) {
+    case 1: VQA_CAND(1); break;
+    case 2: VQA_CAND(2); break;
+    case 3: VQA_CAND(3); break;
+    case 4: VQA_CAND(4); break;
+    case 5: VQA_CAND(5); break;
+    case 6: VQA_CAND(6); break;
+    case 7: VQA_CAND(7); break;
+    default: VQA_CAND(8); break;
+  }
+#undef VQA_CAND
+  return launch_status();
+}
+
+int vqa_abi_version(void) { return 1; }
+
+const char* vqa_error_string(int code) {
+  switch (code) {
+    case VQA_OK: return "ok";
+    case VQA_ERR_NULL: return "a required pointer is NULL";
+    case VQA_ERR_SHAPE: return "a count/stride/option argument is out of the supported range";
+    case VQA_ERR_ALIGN: return "a pointer is not aligned as required";
+    default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown vqattack error";
+  }
+}
+
+}  // extern "C"

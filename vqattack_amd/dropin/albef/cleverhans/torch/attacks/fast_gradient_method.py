@@ -1,0 +1,7 @@
+"""Same module path as the reference's attacks/fast_gradient_method.py (albef copy)."""
+import functools
+
+from vqattack_amd import attacks as _impl
+
+fast_gradient_method = functools.wraps(_impl.fast_gradient_method)(
+    functools.partial(_impl.fast_gradient_method, flavor="albef"))

@@ -1,0 +1,7 @@
+"""Same module path as the reference's attacks/projected_gradient_descent_vl.py (albef copy)."""
+import functools
+
+from vqattack_amd import attacks as _impl
+
+projected_gradient_descent = functools.wraps(_impl.projected_gradient_descent_vl)(
+    functools.partial(_impl.projected_gradient_descent_vl, flavor="albef"))

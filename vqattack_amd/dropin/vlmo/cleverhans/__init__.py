@@ -1,0 +1,1 @@
+"""Drop-in `cleverhans` package (vlmo flavor) backed by vqattack_amd -- see vqattack_amd/dropin/__init__.py."""

@@ -1,0 +1,338 @@
+"""Tensor-level wrappers over the C ABI (one function per kernel entry point).
+
+Every function launches on the current HIP stream of its tensors' device and returns without synchronising.
+``out=`` arguments let the PGD loop ping-pong between two pre-allocated image buffers.
+"""
+import contextlib
+import ctypes
+import math
+
+import torch
+
+from . import _hip
+from ._hip import VQA_CHECK_RANGE, VQA_CLIP, check, dev_f32, lib, ptr, same_device, stream_for
+
+_INF = float("inf")
+
+
+@contextlib.contextmanager
+def _on(t):
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        with torch.cuda.device(t.device):
+            yield
+    else:
+        yield
+
+
+def _clip_args(clip_min, clip_max):
+    """(mode bits, cmin, cmax); a missing bound becomes +-inf (torch.clamp with one bound)."""
+    if clip_min is None and clip_max is None:
+        return 0, -_INF, _INF
+    return VQA_CLIP, (-_INF if clip_min is None else float(clip_min)), (_INF if clip_max is None else float(clip_max))
+
+
+def _out_like(x, out):
+    if out is None:
+        return torch.empty_like(x, memory_format=torch.contiguous_format)
+    dev_f32(out, "out")
+    if out.shape != x.shape:
+        raise ValueError("out has shape {}, expected {}".format(tuple(out.shape), tuple(x.shape)))
+    return out
+
+
+def new_flag(device):
+    """int32[1] device word the kernels OR range violations into (read once at the end of an attack)."""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+# ----------------------------------------------------------------------------------------- L-inf
+def linf_init(x, eta, eps, clip_min, clip_max, flag=None, out=None):
+    dev_f32(x, "x")
+    if eta is not None:
+        dev_f32(eta, "eta")
+        if eta.shape != x.shape:
+            raise ValueError("eta shape {} != x shape {}".format(tuple(eta.shape), tuple(x.shape)))
+    same_device(x, eta, out, flag)
+    out = _out_like(x, out)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    if flag is not None and mode:
+        mode |= VQA_CHECK_RANGE
+    with _on(x):
+        check(lib().vqa_linf_init(ptr(x), ptr(eta), ptr(out), x.numel(), eps, lo, hi, mode, ptr(flag),
+                                  stream_for(x)), "vqa_linf_init")
+    return out
+
+
+def linf_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
+    dev_f32(x, "x"), dev_f32(g, "grad")
+    if g.shape != x.shape:
+        raise ValueError("grad shape {} != x shape {}".format(tuple(g.shape), tuple(x.shape)))
+    same_device(x, g, out, flag)
+    out = _out_like(x, out)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    if flag is not None and mode:
+        mode |= VQA_CHECK_RANGE
+    with _on(x):
+        check(lib().vqa_linf_fgm(ptr(x), ptr(g), ptr(out), x.numel(), eps_iter, lo, hi, mode, ptr(flag),
+                                 stream_for(x)), "vqa_linf_fgm")
+    return out
+
+
+def linf_step(x, g, x0, eps_iter, eps, clip_min, clip_max, flag=None, out=None):
+    """The fused north-star kernel: FGM update + eps-ball projection + clamp, 16 B/element."""
+    dev_f32(x, "x"), dev_f32(g, "grad"), dev_f32(x0, "ori_x")
+    if g.shape != x.shape or x0.shape != x.shape:
+        raise ValueError("shape mismatch: x {}, grad {}, ori_x {}".format(tuple(x.shape), tuple(g.shape),
+                                                                          tuple(x0.shape)))
+    same_device(x, g, x0, out, flag)
+    out = _out_like(x, out)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    if flag is not None and mode:
+        mode |= VQA_CHECK_RANGE
+    with _on(x):
+        check(lib().vqa_linf_step(ptr(x), ptr(g), ptr(x0), ptr(out), x.numel(), eps_iter, eps, lo, hi, mode,
+                                  ptr(flag), stream_for(x)), "vqa_linf_step")
+    return out
+
+
+def linf_project(adv, x0, eps, clip_min, clip_max, out=None):
+    dev_f32(adv, "adv_x"), dev_f32(x0, "ori_x")
+    if adv.shape != x0.shape:
+        raise ValueError("shape mismatch: adv {}, ori_x {}".format(tuple(adv.shape), tuple(x0.shape)))
+    same_device(adv, x0, out)
+    out = _out_like(adv, out)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    with _on(adv):
+        check(lib().vqa_linf_project(ptr(adv), ptr(x0), ptr(out), adv.numel(), eps, lo, hi, mode,
+                                     stream_for(adv)), "vqa_linf_project")
+    return out
+
+
+def clip_eta_linf(eta, eps):
+    dev_f32(eta, "eta")
+    out = torch.empty_like(eta)
+    with _on(eta):
+        check(lib().vqa_clip_eta_linf(ptr(eta), ptr(out), eta.numel(), eps, stream_for(eta)), "vqa_clip_eta_linf")
+    return out
+
+
+def optimize_linear_linf(grad, eps):
+    dev_f32(grad, "grad")
+    out = torch.empty_like(grad)
+    with _on(grad):
+        check(lib().vqa_optimize_linear_linf(ptr(grad), ptr(out), grad.numel(), eps, stream_for(grad)),
+              "vqa_optimize_linear_linf")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- per-sample norms
+def _per_sample(t):
+    batch = t.shape[0] if t.dim() > 0 else 1
+    n_per = t.numel() // max(batch, 1)
+    return batch, n_per
+
+
+def _workspace(t):
+    batch, n_per = _per_sample(t)
+    nbytes = lib().vqa_reduce_ws_bytes(batch, n_per)
+    return torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=t.device)
+
+
+def sumsq_per_sample(t, sub=None):
+    """out[b] = sum((t[b] - sub[b])**2), deterministic two-stage reduction."""
+    dev_f32(t, "t")
+    if sub is not None:
+        dev_f32(sub, "sub")
+        if sub.shape != t.shape:
+            raise ValueError("shape mismatch")
+    batch, n_per = _per_sample(t)
+    out = torch.empty(batch, dtype=torch.float32, device=t.device)
+    ws = _workspace(t)
+    with _on(t):
+        check(lib().vqa_sumsq_per_sample(ptr(t), ptr(sub), ptr(out), batch, n_per, ptr(ws), stream_for(t)),
+              "vqa_sumsq_per_sample")
+    return out
+
+
+def absmax_ties_per_sample(g):
+    dev_f32(g, "grad")
+    batch, n_per = _per_sample(g)
+    amax = torch.empty(batch, dtype=torch.float32, device=g.device)
+    ties = torch.empty(batch, dtype=torch.float32, device=g.device)
+    ws = _workspace(g)
+    with _on(g):
+        check(lib().vqa_absmax_ties_per_sample(ptr(g), ptr(amax), ptr(ties), batch, n_per, ptr(ws), stream_for(g)),
+              "vqa_absmax_ties_per_sample")
+    return amax, ties
+
+
+def l2_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
+    dev_f32(x, "x"), dev_f32(g, "grad")
+    if g.shape != x.shape:
+        raise ValueError("shape mismatch")
+    ss = sumsq_per_sample(g)
+    out = _out_like(x, out)
+    batch, n_per = _per_sample(x)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    if flag is not None and mode:
+        mode |= VQA_CHECK_RANGE
+    with _on(x):
+        check(lib().vqa_l2_fgm(ptr(x), ptr(g), ptr(ss), ptr(out), batch, n_per, eps_iter, lo, hi, mode, ptr(flag),
+                               stream_for(x)), "vqa_l2_fgm")
+    return out
+
+
+def l2_project(adv, x0, eps, clip_min, clip_max, out=None):
+    dev_f32(adv, "adv_x"), dev_f32(x0, "ori_x")
+    if adv.shape != x0.shape:
+        raise ValueError("shape mismatch")
+    ss = sumsq_per_sample(adv, sub=x0)
+    out = _out_like(adv, out)
+    batch, n_per = _per_sample(adv)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    with _on(adv):
+        check(lib().vqa_l2_project(ptr(adv), ptr(x0), ptr(ss), ptr(out), batch, n_per, eps, lo, hi, mode,
+                                   stream_for(adv)), "vqa_l2_project")
+    return out
+
+
+def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
+    dev_f32(x, "x"), dev_f32(g, "grad")
+    if g.shape != x.shape:
+        raise ValueError("shape mismatch")
+    amax, ties = absmax_ties_per_sample(g)
+    out = _out_like(x, out)
+    batch, n_per = _per_sample(x)
+    mode, lo, hi = _clip_args(clip_min, clip_max)
+    if flag is not None and mode:
+        mode |= VQA_CHECK_RANGE
+    with _on(x):
+        check(lib().vqa_l1_fgm(ptr(x), ptr(g), ptr(amax), ptr(ties), ptr(out), batch, n_per, eps_iter, lo, hi, mode,
+                               ptr(flag), stream_for(x)), "vqa_l1_fgm")
+    return out
+
+
+def scale_per_sample(t, stat, stat2, eps, kind, out=None):
+    dev_f32(t, "t"), dev_f32(stat, "stat")
+    out = _out_like(t, out)
+    batch, n_per = _per_sample(t)
+    with _on(t):
+        check(lib().vqa_scale_per_sample(ptr(t), ptr(stat), ptr(stat2), ptr(out), batch, n_per, eps, kind,
+                                         stream_for(t)), "vqa_scale_per_sample")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- loss
+_COS_EPS = 1e-6   # nn.CosineSimilarity(eps=1e-6) in the reference
+_partials = {}
+
+
+def _partial_buf(device):
+    buf = _partials.get(device)
+    if buf is None:
+        buf = torch.empty(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
+        _partials[device] = buf
+    return buf
+
+
+def _rows_view(t, name):
+    """(rows0, rows1, D, stride0, stride1) of a 2-d or 3-d fp32 tensor whose last dim is dense."""
+    if t.dim() == 2:
+        r0, r1, d = 1, t.shape[0], t.shape[1]
+        s0, s1 = 0, t.stride(0)
+    elif t.dim() == 3:
+        r0, r1, d = t.shape
+        s0, s1 = t.stride(0), t.stride(1)
+    else:
+        raise ValueError("{} must be 2-d (rows, D) or 3-d (rows0, rows1, D), got {}".format(name, tuple(t.shape)))
+    return r0, r1, d, s0, s1
+
+
+def _kernel_ready(t):
+    if t.dim() < 2:
+        return False
+    if t.stride(-1) != 1 and t.shape[-1] > 1:
+        return False
+    if t.data_ptr() % 16:
+        return False
+    return all(s % 4 == 0 for s in t.stride()[:-1])
+
+
+def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_mask=None, mask_period=1):
+    """loss_out[0] (+)= gscale * sum_rows -cos(a_row, b_row); returns d(that)/d a (same shape as ``a``) or None.
+
+    ``a`` / ``b`` may be strided views (the reference's ``[:, :feat_len, :]`` truncations) as long as rows are
+    dense.  ``loss_out`` is a 1-element fp32 device tensor (a slot of the attack's loss buffer).
+    """
+    dev_f32(a, "out", contiguous=False), dev_f32(b, "y", contiguous=False)
+    if a.shape != b.shape:
+        raise ValueError("feature/target shape mismatch: {} vs {}".format(tuple(a.shape), tuple(b.shape)))
+    d = a.shape[-1]
+    if d % 4 or d > 2048:
+        raise _hip.HipExtensionError("feature dim {} unsupported by vqa_neg_cos_rows (multiple of 4, <= 2048)".format(d))
+    if not _kernel_ready(a):
+        a = a.contiguous()
+    if not _kernel_ready(b):
+        b = b.contiguous()
+    r0, r1, d, a0, a1 = _rows_view(a, "out")
+    _, _, _, b0, b1 = _rows_view(b, "y")
+    ga = None
+    g0 = g1 = 0
+    if want_grad:
+        ga = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+        _, _, _, g0, g1 = _rows_view(ga, "grad")
+    if row_mask is not None:
+        if row_mask.dtype != torch.uint8 or not row_mask.is_cuda or not row_mask.is_contiguous():
+            raise TypeError("row_mask must be a contiguous uint8 device tensor")
+        if row_mask.numel() != mask_period * r1:
+            raise ValueError("row_mask has {} entries, expected mask_period*rows1 = {}".format(
+                row_mask.numel(), mask_period * r1))
+    part = _partial_buf(a.device)
+    with _on(a):
+        st = stream_for(a)
+        check(lib().vqa_neg_cos_rows(ptr(a), ptr(b), ptr(ga), ptr(part), ptr(row_mask), mask_period, r0, r1, d,
+                                     a0, a1, b0, b1, g0, g1, gscale, _COS_EPS, st), "vqa_neg_cos_rows")
+        check(lib().vqa_sum_partials(ptr(part), part.numel(), ptr(loss_out), 1 if accumulate else 0, gscale, st),
+              "vqa_sum_partials")
+    return ga
+
+
+# ----------------------------------------------------------------------------------------- text side
+def gather_rows(src, index):
+    """src (B, L, D)[:, index] -> (B, K, D)."""
+    dev_f32(src, "text gradient")
+    if src.dim() != 3:
+        raise ValueError("text gradient must be (B, L, D)")
+    if not isinstance(index, torch.Tensor):
+        index = torch.as_tensor(list(index), dtype=torch.int64)
+    b, l, d = src.shape
+    host = index.detach().cpu().to(torch.int64)
+    if host.numel() and (int(host.max()) >= l or int(host.min()) < -l):
+        raise IndexError("index out of range for dimension 1 with size {}".format(l))
+    idx = host.to(src.device)
+    k = idx.numel()
+    dst = torch.empty((b, k, d), dtype=torch.float32, device=src.device)
+    with _on(src):
+        check(lib().vqa_gather_rows(ptr(src), ctypes.c_void_p(idx.data_ptr()), ptr(dst), b, l, k, d,
+                                    stream_for(src)), "vqa_gather_rows")
+    return dst
+
+
+def cand_dir_sim(word, pos, type_emb, gamma, beta, ln_eps, e_ori, grad, cand):
+    """Scores of candidate substitutions, one fp32 per row of ``cand`` (int32 (n, 4) = sample, position, grad row, id)."""
+    for name, t in (("word", word), ("pos", pos), ("type", type_emb), ("gamma", gamma), ("beta", beta),
+                    ("e_ori", e_ori), ("grad", grad)):
+        dev_f32(t, name)
+    if cand.dtype != torch.int32 or cand.dim() != 2 or cand.shape[1] != 4 or not cand.is_cuda:
+        raise TypeError("cand must be an int32 (n, 4) device tensor")
+    cand = cand.contiguous()
+    n = cand.shape[0]
+    d = word.shape[1]
+    _, l, _ = e_ori.shape
+    _, k, _ = grad.shape
+    out = torch.empty(n, dtype=torch.float32, device=word.device)
+    with _on(word):
+        check(lib().vqa_cand_dir_sim(ptr(word), ptr(pos), ptr(type_emb), ptr(gamma), ptr(beta), ln_eps, ptr(e_ori),
+                                     ptr(grad), ctypes.c_void_p(cand.data_ptr()), ptr(out), n, l, k, d,
+                                     stream_for(word)), "vqa_cand_dir_sim")
+    return out

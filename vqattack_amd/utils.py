@@ -1,0 +1,49 @@
+"""``cleverhans.torch.utils`` of the reference, on the HIP kernels.
+
+Reference: ``ALBEF_VQAttack/cleverhans/cleverhans/torch/utils.py`` -- ``clip_eta`` :8-40, ``optimize_linear`` :70-128
+(the VLMO copy is arithmetically identical).  Same signatures, return values and exceptions.  Two deliberate
+differences, both host-sync removals: the reference's self-check ``assert``s inside ``optimize_linear`` (L1: unit
+L1 norm, L2: unit L2 norm; :101-104, :110-116) are not evaluated -- they can only fire on an all-zero (L1) or
+non-finite gradient and cost a device->host round trip per call.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._hip import dev_f32
+
+
+def _device_tensor(t, name):
+    dev_f32(t, name, contiguous=False)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def clip_eta(eta, norm, eps):
+    """Project ``eta`` on the eps-ball.  L-inf: returns a new tensor; L2: rescales ``eta`` IN PLACE and returns it
+    (as the reference's ``eta *= factor``); L1: ``NotImplementedError``; other norms: ``ValueError``."""
+    if norm not in (np.inf, 1, 2):
+        raise ValueError("norm must be np.inf, 1, or 2.")
+    if norm == 1:
+        raise NotImplementedError("L1 clip is not implemented.")
+    if norm == np.inf:
+        return ops.clip_eta_linf(_device_tensor(eta, "eta"), eps)
+    dev_f32(eta, "eta", contiguous=False)
+    work = eta if eta.is_contiguous() else eta.contiguous()
+    ops.scale_per_sample(work, ops.sumsq_per_sample(work), None, eps, kind=0, out=work)
+    if work is not eta:
+        eta.copy_(work)
+    return eta
+
+
+def optimize_linear(grad, eps, norm=np.inf):
+    """argmax_{|eta|_norm <= eps} <eta, grad>: eps*sign (inf), eps*grad/|grad|_2 (2), eps*sign*[|g|==max]/ties (1)."""
+    if norm == np.inf:
+        return ops.optimize_linear_linf(_device_tensor(grad, "grad"), eps)
+    if norm == 1:
+        g = _device_tensor(grad, "grad")
+        amax, ties = ops.absmax_ties_per_sample(g)
+        return ops.scale_per_sample(g, amax, ties, eps, kind=2)
+    if norm == 2:
+        g = _device_tensor(grad, "grad")
+        return ops.scale_per_sample(g, ops.sumsq_per_sample(g), None, eps, kind=1)
+    raise NotImplementedError("Only L-inf, L1 and L2 norms are currently implemented.")
