@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- adversarial VQA examples/sec of the MI355X-native VQAttack PGD path.
+
+Contract (see the task description): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver starts
+it under ``python -m torch.distributed.run`` (one rank per GPU, RCCL).  A *step* is one full attack of one batch:
+BASELINE.json configs[1] -- VLMO-base white box (random-init, frozen, fp32), batch 64, 40 PGD steps, 384x384 images,
+40-token questions, eps 0.125 / step 0.01 / clip [-1, 1] (the reference's literals) -- followed by black-box scoring and,
+for N > 1, the RCCL all-gather of attack-success bits.  Inputs are synthetic and resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line with the aggregate examples/sec over all ranks (weak scaling: every rank attacks
+its own batch of 64), plus
+
+  * ``roofline``: the fused sign+clamp+project kernel (``vqa_linf_step``), timed live with HIP events on the launch
+    stream inside the timed region; achieved = 16 B/element x elements per launch / mean launch duration, against the
+    8 TB/s HBM3E peak; ``roofline_b256`` repeats it at the batch the north-star target is stated for.
+  * ``cpu_baseline``: the CPU oracle (reference op chain, reference-style batch-1 adapters) on the host cores, on a
+    bounded sample (1 image, a few of the 40 steps, extrapolated), rank 0 / N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a float4 copy reaches
+STEP_BYTES_PER_ELEM = 16    # read x, grad, x0 + write x' 
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--pgd-steps", type=int, default=40)
+    ap.add_argument("--image-size", type=int, default=384)
+    ap.add_argument("--model", default="vlmo_base", choices=["vlmo_base", "vlmo_large", "vlmo_tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=4)
+    ap.add_argument("--no-b256", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_questions(batch, length, n_body, seed, device):
+    """[CLS] + body ids U{1000..30521} + [SEP] + padding."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(batch, length, dtype=torch.long)
+    ids[:, 0] = 101
+    ids[:, 1:1 + n_body] = torch.randint(1000, 30522, (batch, n_body), generator=g)
+    ids[:, 1 + n_body] = 102
+    return ids.to(device), (ids != 0).long().to(device)
+
+
+def make_config(args):
+    from vqattack_amd.whitebox import vlmo
+    if args.model == "vlmo_tiny":
+        return vlmo.vlmo_tiny()
+    return getattr(vlmo, args.model)(image_size=args.image_size)
+
+
+class StepKernelTimer:
+    """HIP-event timing of every ``vqa_linf_step`` launch, on the stream the kernel is launched on."""
+
+    def __init__(self):
+        self.events, self.numel = [], 0
+
+    def install(self):
+        from vqattack_amd import ops
+        self._orig = ops.linf_step
+        timer = self
+
+        def timed(x, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                       # torch's current stream == the launch stream (ops.stream_for)
+            out = timer._orig(x, *a, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            timer.numel = x.numel()
+            return out
+        ops.linf_step = timed
+
+    def remove(self):
+        from vqattack_amd import ops
+        ops.linf_step = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        if not ms:
+            return None
+        mean_ms = sum(ms) / len(ms)
+        nbytes = STEP_BYTES_PER_ELEM * self.numel
+        gbs = nbytes / mean_ms / 1e6
+        return dict(kernel="vqa_linf_step (stream4_kernel<StepOp>)", bound="hbm", achieved=round(gbs, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                    launches=len(ms), mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min(ms) * 1e3, 2),
+                    algorithmic_bytes_per_launch=nbytes, timing="hip events on the launch stream, per launch")
+
+
+def step_kernel_microbench(batch, image_size, reps=40):
+    """Back-to-back launches of the fused step at `batch` (north-star target batch 256), one event pair around all."""
+    from vqattack_amd import ops
+    shape = (batch, 3, image_size, image_size)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.empty(shape, device="cuda").uniform_(-1, 1, generator=gen)
+    x = torch.clamp(x0 + torch.empty(shape, device="cuda").uniform_(-0.125, 0.125, generator=gen), -1, 1)
+    g = torch.randn(shape, device="cuda", generator=gen)
+    bufs = [x, torch.empty_like(x)]
+    for i in range(4):
+        ops.linf_step(bufs[i & 1], g, x0, 0.01, 0.125, -1, 1, out=bufs[1 - (i & 1)])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        ops.linf_step(bufs[i & 1], g, x0, 0.01, 0.125, -1, 1, out=bufs[1 - (i & 1)])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = STEP_BYTES_PER_ELEM * x.numel()
+    gbs = nbytes / ms / 1e6
+    return dict(kernel="vqa_linf_step", batch=batch, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), mean_launch_us=round(ms * 1e3, 2),
+                algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps))
+
+
+def cpu_baseline(args, cfg):
+    """The reference's CPU path (oracle restatement + reference-style batch-1 packing) on the host cores."""
+    import numpy as np
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import VlmoRefAdapters
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = FrozenVlmo(cfg, seed=0)
+    ids, masks = synthetic_questions(1, cfg.max_text_len, 8, seed=0, device="cpu")
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.empty(1, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    ad = VlmoRefAdapters(model, ids, masks)
+    y = ad.gen_ori_feats(x0)
+    steps = max(1, min(args.cpu_baseline_steps, args.pgd_steps))
+    t0 = time.perf_counter()
+    with torch.enable_grad():
+        oracle.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, steps, np.inf, clip_min=-1, clip_max=1,
+                                          y=y, ori_x=x0, time=0, ls=1, flavor="vlmo")
+    dt = time.perf_counter() - t0
+    per_example = dt * args.pgd_steps / steps
+    return dict(value=round(1.0 / per_example, 5), unit="examples/s", cores=cores, kind="port",
+                sample="1 image x {} of {} PGD steps ({:.1f} s), extrapolated to {} steps; oracle/cleverhans_cpu.py + "
+                       "reference-style batch-1 adapter on torch CPU fp32".format(steps, args.pgd_steps, dt,
+                                                                                  args.pgd_steps))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the attack path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from vqattack_amd.attack.asr import SuccessLedger
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters
+
+    cfg = make_config(args)
+    white = FrozenVlmo(cfg, seed=0).to(device)
+    black = FrozenVlmo(cfg, seed=1, vqa_head=True).to(device)
+    adapters = VlmoAttackAdapters(white)
+    attack = BatchedVQAttack(adapters, "vlmo", white.embedding_tables(),
+                             AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
+    ledger = SuccessLedger(world, rank, device)
+
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    images = torch.empty(args.batch, 3, cfg.image_size, cfg.image_size, device=device).uniform_(-1, 1, generator=gen)
+    ids, masks = synthetic_questions(args.batch, cfg.max_text_len, 8, seed=100 + rank, device=device)
+    no_words = torch.zeros_like(ids, dtype=torch.bool)           # configs[1]: image-only 40-step PGD
+    clean_answers = black.vqa_answer(images, ids, masks)
+
+    def one_step():
+        res = attack.attack_batch(images, ids, masks, no_words)
+        adv_answers = black.vqa_answer(res.adv_images, res.adv_text_ids, masks)
+        ledger.record(adv_answers != clean_answers)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    ledger.reset()
+    timer = StepKernelTimer()
+    timer.install()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    asr = ledger.all_gather_rate()            # RCCL all-gather of the success bits (N > 1); inside the timed region
+    fence()
+    dt = time.perf_counter() - t0
+    timer.remove()
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    roof = timer.summary()
+
+    if rank == 0:
+        total = world * args.batch * args.steps
+        line = {
+            "metric": "adversarial_vqa_examples_per_sec", "value": round(total / dt, 4), "unit": "examples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "{} VQAttack image PGD (BASELINE configs[1]): batch {} per GPU, {} PGD steps, "
+                                   "{}x{} images, {}-token questions, eps 0.125 step 0.01 L-inf clip [-1,1], random start, "
+                                   "black-box scoring + ASR gather".format(args.model, args.batch, args.pgd_steps,
+                                                                           cfg.image_size, cfg.image_size,
+                                                                           cfg.max_text_len),
+                       "batch_per_gpu": args.batch, "pgd_steps": args.pgd_steps, "image_size": cfg.image_size,
+                       "text_len": cfg.max_text_len, "sharding": "independent batches per rank, all-gather of success bits"},
+            "attack_success_rate": asr,
+            "roofline": roof,
+        }
+        if not args.no_b256:
+            try:
+                line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
+            except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
+                line["roofline_b256"] = {"error": str(exc)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

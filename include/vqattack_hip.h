@@ -123,8 +123,9 @@ int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, 
  * (torch.nn.CosineSimilarity semantics of torch 2.x).  The kernel accumulates  -c  per block into
  * partial[] and, when ga != NULL, writes d(gscale * sum(-c)) / d a  into ga (same addressing as a, with its own
  * strides) -- loss value and the gradient w.r.t. the model output in ONE pass over a and b.
- * row_mask (nullable, uint8): rows with row_mask[(o % mask_period) * rows1 + i] == 0 contribute nothing and get a
- * zero gradient (padded text tokens of a batched VLMO adapter).
+ * row_mask (nullable, uint8 row WEIGHTS): row (o, i) is weighted by w = row_mask[(o % mask_period) * rows1 + i];
+ * w == 0 rows are not even loaded and get a zero gradient (padded text tokens of a batched adapter), w == 2 counts a
+ * row twice (the VLMO loss takes the [CLS] row both on its own and as a token, V-ch/attacks/fast_gradient_method.py:111).
  * Replaces nn.CosineSimilarity + negate + two torch.sum calls and their autograd backward:
  * A-ch/attacks/fast_gradient_method.py:98,120-127; V-ch/attacks/fast_gradient_method.py:102-114.
  * D must be a multiple of 4 and <= 2048; a, b, ga 16-byte aligned with strides multiples of 4.

@@ -33,16 +33,19 @@ UTIL_CASES = [
     dict(name="optlin_l1", op="optimize_linear", norm=1, eps=1.5, seed=106),
 ]
 
+# NB: no case starts a time != 0 run exactly at the clean image: there out == y, the cosine loss sits at its
+# maximum and the gradient is pure rounding noise, so its sign -- hence the trajectory -- is not reproducible
+# across devices.  The reference avoids that point itself by drawing a random start for the first block (time=0).
 ATTACK_CASES = [
     # BASELINE.json configs[0]: 4 images x 10 steps, eps = 8/255 (step 2/255), clip [-1, 1]
     dict(name="albef_pgd_linf_cfg0", flavor="albef", op="pgd", batch=4, steps=10, eps=8 / 255,
-         eps_iter=2 / 255, norm="inf", ls=1, time=1, start_inside=False),
+         eps_iter=2 / 255, norm="inf", ls=1, time=0, start_inside=False, seed=1234),
     dict(name="albef_pgd_linf_ref_literals", flavor="albef", op="pgd", batch=2, steps=6, eps=0.125,
          eps_iter=0.01, norm="inf", ls=1, time=1, start_inside=True, y_extra=2),
     dict(name="albef_pgd_linf_randinit", flavor="albef", op="pgd", batch=2, steps=4, eps=0.125,
          eps_iter=0.01, norm="inf", ls=1, time=0, start_inside=False, seed=77),
     dict(name="albef_pgd_l2", flavor="albef", op="pgd", batch=3, steps=5, eps=2.0, eps_iter=0.5,
-         norm=2, ls=1, time=1, start_inside=False),
+         norm=2, ls=1, time=1, start_inside=True),
     dict(name="albef_pgd_dual", flavor="albef", op="pgd", batch=2, steps=3, eps=0.125, eps_iter=0.01,
          norm="inf", ls=0, time=1, start_inside=True, labels="2d"),
     dict(name="albef_pgd_dual_3d", flavor="albef", op="pgd", batch=1, steps=2, eps=0.125,

@@ -31,7 +31,7 @@ def _grad(shape, seed):
     g = r.standard_normal(shape).astype(np.float32)
     flat = g.reshape(-1)
     n = flat.size
-    idx = r.choice(n, size=max(n // 50, 4), replace=False)
+    idx = r.choice(n, size=min(n, max(n // 50, 4)), replace=False)
     flat[idx[0::4]] = 0.0
     flat[idx[1::4]] = -0.0
     flat[idx[2::4]] = np.nan
@@ -252,10 +252,11 @@ def test_neg_cos_rows_strided_views_2d_and_mask():
     assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
     # row mask with period 2 over the outer axis (layer-major packing of a batch of 2)
     mask = torch.from_numpy((r.uniform(size=(2, 20)) > 0.3).astype(np.uint8))
+    mask[0, 0] = 2                                           # a row counted twice (VLMO [CLS])
     a3, b3 = full_a, full_b[:, :20].contiguous()
     m_full = mask.repeat(3, 1).float()                       # outer index o -> mask row o % 2
     want_loss, want_grad = _cos_ref(a3, b3, m_full)
-    ga = ops.neg_cos_rows(a3.to(DEV), b3.to(DEV), slot, accumulate=False, row_mask=mask.to(DEV), mask_period=2)
+    ga = ops.neg_cos_rows(a3.to(DEV), b3.to(DEV), slot, accumulate=False, row_weight=mask.to(DEV), weight_period=2)
     assert torch.allclose(slot.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
     assert torch.allclose(ga.cpu(), want_grad, rtol=1e-4, atol=1e-6)
 

@@ -8,7 +8,12 @@ launches per measurement, ping-ponging x/out so every launch reads and writes fr
 import argparse
 import json
 
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from vqattack_amd import _hip, ops
 

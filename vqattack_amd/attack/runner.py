@@ -1,0 +1,139 @@
+"""Batched VQAttack driver: the block loop of the reference's orchestrators on top of the drop-in operators.
+
+Reference control flow (one sample at a time, batch 1): ``Adv_attack.evaluate``, ``ALBEF_attack/adv_attack.py:560-716``
+and ``VLMo.test_step``, ``vlmo/modules/vlmo_module.py:1893-2062``:
+
+    targets  = Gen_ori_feats(clean image, clean question)
+    blocks   = cal_text_attack_list(question)                      # schedule.iter_schedule + MLM candidates
+    no substitutable word:  one PGD of 40 steps (20 dual-loss iterations)
+    else for each block i:  re-tokenise adv text; PGD(nb_iter = blocks[i], time = 0 only for i == 0)
+                            unless last: pgd_vl(1 step, attack_mask) -> update_adv_text
+    score (adv image, adv text) with the black box; success = answer differs from the clean answer
+
+Here the same flow runs for a whole batch whose samples share a schedule (``schedule.bucket_by_schedule``); the
+operators are the shipped HIP path (``vqattack_amd.dropin``), the white box is any adapter object exposing the
+reference's closures (``pgd_attack``, ``pgd_attack_vl``, ``pgd_mlm_attack``, ``gen_ori_feats``, ``set_text``).
+Attack hyper-parameters default to the reference's hard-coded literals (adv_attack.py:607-610: eps 0.125, step 0.01,
+L-inf, clip [-1, 1]).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .. import dropin
+from . import text_update
+from .schedule import IMAGE_STEP_BUDGET, iter_schedule
+
+
+@dataclass
+class AttackConfig:
+    eps: float = 0.125
+    eps_iter: float = 0.01
+    budget: int = IMAGE_STEP_BUDGET
+    clip_min: float = -1.0
+    clip_max: float = 1.0
+    norm: float = np.inf
+    random_start: bool = True          # first block uses time=0 (uniform start), like the reference
+    sanity_checks: bool = False        # the flag read is a host sync; parity tests switch it on
+
+
+@dataclass
+class BatchResult:
+    adv_images: torch.Tensor
+    adv_text_ids: torch.Tensor
+    loss_lists: list = field(default_factory=list)
+    substitutions: list = field(default_factory=list)
+    gradient_steps: int = 0
+
+
+class BatchedVQAttack:
+    def __init__(self, adapters, flavor, tables, config=None, similarity_fn=None, banned_ids=None):
+        self.adapters = adapters
+        self.flavor = flavor
+        self.tables = tables                     # embedding tables for the candidate-scoring kernel
+        self.cfg = config or AttackConfig()
+        self.similarity_fn = similarity_fn or text_update.BagOfEmbeddingsSimilarity()
+        self.banned_ids = banned_ids
+        ns = dropin.load(flavor)
+        self.pgd = ns.projected_gradient_descent.projected_gradient_descent
+        self.pgd_vl = ns.projected_gradient_descent_vl.projected_gradient_descent
+
+    # the y lists the reference passes (adv_attack.py:609,637; vlmo_module.py:1948,1975)
+    def _y_feature(self, targets):
+        if self.flavor == "albef":
+            return [targets[0], targets[1], None, None, None]
+        return [targets[0], targets[1], targets[2]]
+
+    def _y_dual(self, targets, mlm_labels):
+        if self.flavor == "albef":
+            return [mlm_labels, targets[0], targets[1]]
+        return [mlm_labels, targets[1], targets[2]]
+
+    def _pgd_block(self, adv, clean, targets, steps, time, dual, mlm_labels, init_eta=None):
+        c = self.cfg
+        common = dict(clip_min=c.clip_min, clip_max=c.clip_max, time=time, ori_x=clean,
+                      sanity_checks=c.sanity_checks, init_eta=init_eta)
+        a = self.adapters
+        if not dual:
+            return self.pgd(a.pgd_attack, adv, c.eps, c.eps_iter, steps, c.norm, y=self._y_feature(targets), ls=1,
+                            **common)
+        return self.pgd([a.pgd_attack, a.pgd_mlm_attack], adv, c.eps, c.eps_iter, steps // 2, c.norm,
+                        y=self._y_dual(targets, mlm_labels), ls=0, **common)
+
+    @torch.no_grad()
+    def attack_batch(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, dual=False,
+                     mlm_labels=None, init_eta=None):
+        """Attack one batch whose samples all have the same number of attackable words.
+
+        images (B,3,H,W) in [clip_min, clip_max]; text_ids/text_masks (B,L); attackable bool (B,L) with the same
+        count per row.  ``mlm_logits_fn(text_ids, text_masks) -> (B,L,V)`` proposes substitution candidates (the
+        reference uses a separate HF BERT-MLM, adv_attack.py:110,242).  Returns a ``BatchResult``.
+        """
+        c, a = self.cfg, self.adapters
+        n_words = int(attackable[0].sum().item())
+        if not bool((attackable.sum(dim=1) == n_words).all()):
+            raise ValueError("samples of one batch must share a schedule: bucket them with bucket_by_schedule()")
+        blocks = iter_schedule(n_words, c.budget)
+        a.set_text(text_ids, text_masks)
+        targets = a.gen_ori_feats(images)
+        adv = images
+        adv_ids = text_ids.clone()
+        res = BatchResult(adv_images=adv, adv_text_ids=adv_ids)
+        first_time = 0 if c.random_start else 1
+        if not blocks:
+            with torch.enable_grad():
+                adv, losses = self._pgd_block(adv, images, targets, c.budget, first_time, dual, mlm_labels, init_eta)
+            res.loss_lists.append(losses)
+            res.gradient_steps = c.budget
+        else:
+            proposals = None
+            if mlm_logits_fn is not None:
+                proposals = text_update.propose_candidates(mlm_logits_fn(text_ids, text_masks), text_ids, attackable,
+                                                           banned=self.banned_ids)
+            e_ori = a.text_embeddings(text_ids)
+            ori_host = text_ids.cpu().numpy()
+            positions = list(range(text_ids.shape[1]))
+            for bi, steps in enumerate(blocks):
+                a.set_text(adv_ids, text_masks)
+                with torch.enable_grad():
+                    adv, losses = self._pgd_block(adv, images, targets, steps, first_time if bi == 0 else 1, dual,
+                                                  mlm_labels, init_eta if bi == 0 else None)
+                res.loss_lists.append(losses)
+                res.gradient_steps += steps
+                if bi == len(blocks) - 1:
+                    break
+                with torch.enable_grad():
+                    adv, text_grad = self.pgd_vl(a.pgd_attack_vl, [adv, a.text_embeddings(adv_ids)], c.eps, c.eps_iter,
+                                                 1, c.norm, clip_min=c.clip_min, clip_max=c.clip_max,
+                                                 y=self._y_feature(targets), time=1, ori_x=images, ls=1,
+                                                 attack_mask=positions, sanity_checks=c.sanity_checks)
+                res.gradient_steps += 1
+                if proposals is not None:
+                    cand, scores = text_update.score_candidates(self.tables, e_ori, text_grad, proposals)
+                    new_ids, subs = text_update.greedy_accept(cand, scores, ori_host, adv_ids.cpu().numpy(),
+                                                              self.similarity_fn)
+                    adv_ids = torch.as_tensor(new_ids, device=text_ids.device, dtype=text_ids.dtype)
+                    res.substitutions.append(subs)
+        res.adv_images, res.adv_text_ids = adv, adv_ids
+        return res

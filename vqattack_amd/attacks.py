@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from . import ops
 from ._hip import HipExtensionError, dev_f32
+from .features import LayerFeatures, layer_pairs
 
 ALBEF = "albef"
 VLMO = "vlmo"
@@ -113,6 +114,8 @@ def _feature_pairs(out, y, flavor, vl):
         n = min(out[2].shape[1], y[2].shape[1])
         out[2] = out[2][:, :n, :]
         y[2] = y[2][:, :n, :]
+    if out[1] is None:      # batched adapter: the per-layer [CLS] rows ride in out[2] with row weight 2
+        return [(out[2], y[2])]
     return [(out[1], y[1]), (out[2], y[2])]
 
 
@@ -124,12 +127,14 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra_los
     """
     tensors, grads = [], []
     gscale = sign * extra_scale
-    for k, (o, t) in enumerate(pairs):
+    launches = [trip for (o, t) in pairs for trip in layer_pairs(o, t)]   # one launch per (layer, modality)
+    for k, (o, t, w) in enumerate(launches):
         if not o.is_cuda or not t.is_cuda:
             raise HipExtensionError("model_fn outputs and targets y must be on the HIP device")
         o32 = o if o.dtype == torch.float32 else o.to(torch.float32)
         t32 = t.detach() if t.dtype == torch.float32 else t.detach().to(torch.float32)
-        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=True)
+        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=True,
+                              row_weight=w, weight_period=(o32.shape[0] if w is not None else 1))
         tensors.append(o32)
         grads.append(ga)
     if extra_loss is not None:

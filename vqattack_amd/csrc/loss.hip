@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(const float* __res
   float acc = 0.0f;   // this wave's sum of -cos over its rows (same value in every lane)
   for (long r = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave; r < total; r += wstride) {
     const long o = r / ra.rows1, i = r - o * ra.rows1;
-    const bool live = row_mask ? (row_mask[(o % ra.mask_period) * ra.rows1 + i] != 0) : true;
+    const float w = row_mask ? static_cast<float>(row_mask[(o % ra.mask_period) * ra.rows1 + i]) : 1.0f;
+    const bool live = w != 0.0f;   // wave-uniform: weight-0 rows (padded tokens) are never loaded
     const float* pa = a + o * ra.a0 + i * ra.a1;
     const float* pb = b + o * ra.b0 + i * ra.b1;
     f32x4 va[NCH], vb[NCH];
@@ -73,11 +74,12 @@ __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(const float* __res
     const float na = sqrtf(na2), nb = sqrtf(nb2);
     const float dna = fmaxf(na, cos_eps), dnb = fmaxf(nb, cos_eps);
     const float inv = 1.0f / (dna * dnb);
-    if (live) acc += -(dot * inv);
+    if (live) acc += -(w * (dot * inv));
     if (GRAD) {
       // d(-cos)/da = -( b/(dna*dnb) - [na > eps] * dot/(dna*dnb) * a/na^2 ), scaled by the upstream gscale
-      const float kb = -gscale * inv;
-      const float ka = (na > cos_eps) ? gscale * dot * inv / (na * na) : 0.0f;
+      const float gs = gscale * w;
+      const float kb = -gs * inv;
+      const float ka = (na > cos_eps) ? gs * dot * inv / (na * na) : 0.0f;
       float* pg = ga + o * ra.g0 + i * ra.g1;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {

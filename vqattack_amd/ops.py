@@ -258,11 +258,13 @@ def _kernel_ready(t):
     return all(s % 4 == 0 for s in t.stride()[:-1])
 
 
-def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_mask=None, mask_period=1):
+def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None, weight_period=1):
     """loss_out[0] (+)= gscale * sum_rows -cos(a_row, b_row); returns d(that)/d a (same shape as ``a``) or None.
 
     ``a`` / ``b`` may be strided views (the reference's ``[:, :feat_len, :]`` truncations) as long as rows are
     dense.  ``loss_out`` is a 1-element fp32 device tensor (a slot of the attack's loss buffer).
+    ``row_weight`` (uint8, ``weight_period * rows1`` entries): per-row integer weight, indexed by
+    ``(outer % weight_period, inner)``; 0 drops a row (padded token), 2 counts it twice.
     """
     dev_f32(a, "out", contiguous=False), dev_f32(b, "y", contiguous=False)
     if a.shape != b.shape:
@@ -281,16 +283,16 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_mas
     if want_grad:
         ga = torch.empty(a.shape, dtype=torch.float32, device=a.device)
         _, _, _, g0, g1 = _rows_view(ga, "grad")
-    if row_mask is not None:
-        if row_mask.dtype != torch.uint8 or not row_mask.is_cuda or not row_mask.is_contiguous():
-            raise TypeError("row_mask must be a contiguous uint8 device tensor")
-        if row_mask.numel() != mask_period * r1:
-            raise ValueError("row_mask has {} entries, expected mask_period*rows1 = {}".format(
-                row_mask.numel(), mask_period * r1))
+    if row_weight is not None:
+        if row_weight.dtype != torch.uint8 or not row_weight.is_cuda or not row_weight.is_contiguous():
+            raise TypeError("row_weight must be a contiguous uint8 device tensor")
+        if row_weight.numel() != weight_period * r1:
+            raise ValueError("row_weight has {} entries, expected weight_period*rows1 = {}".format(
+                row_weight.numel(), weight_period * r1))
     part = _partial_buf(a.device)
     with _on(a):
         st = stream_for(a)
-        check(lib().vqa_neg_cos_rows(ptr(a), ptr(b), ptr(ga), ptr(part), ptr(row_mask), mask_period, r0, r1, d,
+        check(lib().vqa_neg_cos_rows(ptr(a), ptr(b), ptr(ga), ptr(part), ptr(row_weight), weight_period, r0, r1, d,
                                      a0, a1, b0, b1, g0, g1, gscale, _COS_EPS, st), "vqa_neg_cos_rows")
         check(lib().vqa_sum_partials(ptr(part), part.numel(), ptr(loss_out), 1 if accumulate else 0, gscale, st),
               "vqa_sum_partials")
@@ -312,6 +314,8 @@ def gather_rows(src, index):
     idx = host.to(src.device)
     k = idx.numel()
     dst = torch.empty((b, k, d), dtype=torch.float32, device=src.device)
+    if k == 0 or b == 0:
+        return dst
     with _on(src):
         check(lib().vqa_gather_rows(ptr(src), ctypes.c_void_p(idx.data_ptr()), ptr(dst), b, l, k, d,
                                     stream_for(src)), "vqa_gather_rows")

@@ -1,0 +1,295 @@
+"""Frozen VLMo-shaped white box (multiway transformer) and its batched attack adapters -- PyTorch-ROCm plumbing.
+
+Architecture follows the reference's ``vlmo/modules/multiway_transformer.py`` (``Attention`` :58-118, ``Block`` :121-201,
+``visual_embed`` :366-380, base/large factories :385-404) and the embedding / head wiring of
+``vlmo/modules/vlmo_module.py`` (``pgd_attack`` :1387-1446, ``pgd_attack_vl`` :1328-1385, ``pgd_mlm_attack`` :1448-1529,
+``vqa_classifier`` :274-279).  Weights are randomly initialised from a seed (no checkpoints exist offline) and frozen;
+only the *shape* of the computation matters for the attack path and the metric.
+
+Differences from the reference that serve the MI355X design (none changes a single-sample result):
+  * adapters are BATCHED: the reference hard-codes batch 1 (``target_feats[0, ...]``); here per-layer features stay
+    ``(B, T+N, D)`` and padded text tokens are excluded with a row-weight mask instead of a ragged gather;
+  * per-layer features are returned as ``LayerFeatures`` (no ``torch.stack`` copy);
+  * the patch embedding is an unfold + GEMM (``F.linear``) instead of a strided ``Conv2d``: its backward w.r.t. the
+    image -- the producer of the gradient the fused step kernel consumes -- is then a plain GEMM;
+  * attention goes through ``F.scaled_dot_product_attention`` with the relative-position bias and key-padding mask
+    folded into one additive mask.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..features import LayerFeatures
+
+
+@dataclass
+class VlmoConfig:
+    dim: int = 768
+    depth: int = 12
+    heads: int = 12
+    vlffn_start: int = 10
+    mlp_ratio: float = 4.0
+    patch: int = 16
+    image_size: int = 384
+    max_text_len: int = 40
+    vocab: int = 30522
+    max_position: int = 512
+    layer_scale: float = 0.1
+    n_answers: int = 3129
+    ln_eps: float = 1e-6
+    bert_ln_eps: float = 1e-12
+
+    @property
+    def n_patches(self):
+        return (self.image_size // self.patch) ** 2
+
+    @property
+    def n_image_tokens(self):
+        return self.n_patches + 1
+
+
+def vlmo_base(image_size=384, **kw):
+    return VlmoConfig(dim=768, depth=12, heads=12, vlffn_start=10, image_size=image_size, **kw)
+
+
+def vlmo_large(image_size=384, **kw):
+    return VlmoConfig(dim=1024, depth=24, heads=16, vlffn_start=21, image_size=image_size, **kw)
+
+
+def vlmo_tiny(**kw):   # test-sized
+    return VlmoConfig(dim=64, depth=3, heads=4, vlffn_start=2, image_size=32, patch=8, max_text_len=8, vocab=30522,
+                      n_answers=17, **kw)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)   # reference: q_bias/v_bias parameters, zero k bias
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, bias):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.heads, c // self.heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias)
+        return self.proj(o.transpose(1, 2).reshape(b, n, c))
+
+
+class Block(nn.Module):
+    def __init__(self, cfg, with_vlffn):
+        super().__init__()
+        hidden = int(cfg.dim * cfg.mlp_ratio)
+        self.norm1 = nn.LayerNorm(cfg.dim, eps=cfg.ln_eps)
+        self.attn = Attention(cfg.dim, cfg.heads)
+        self.norm2_text = nn.LayerNorm(cfg.dim, eps=cfg.ln_eps)
+        self.norm2_imag = nn.LayerNorm(cfg.dim, eps=cfg.ln_eps)
+        self.mlp_text = Mlp(cfg.dim, hidden)
+        self.mlp_imag = Mlp(cfg.dim, hidden)
+        self.mlp_vl = Mlp(cfg.dim, hidden) if with_vlffn else None
+        self.norm2_vl = nn.LayerNorm(cfg.dim, eps=cfg.ln_eps) if with_vlffn else None
+        self.gamma_1 = nn.Parameter(cfg.layer_scale * torch.ones(cfg.dim))
+        self.gamma_2 = nn.Parameter(cfg.layer_scale * torch.ones(cfg.dim))
+        self.max_text_len = cfg.max_text_len
+
+    def forward(self, x, bias):
+        x = x + self.gamma_1 * self.attn(self.norm1(x), bias)
+        if self.mlp_vl is None:     # modality experts: text tokens / image tokens (multiway_transformer.py:193-197)
+            t, i = x[:, :self.max_text_len], x[:, self.max_text_len:]
+            t = t + self.gamma_2 * self.mlp_text(self.norm2_text(t))
+            i = i + self.gamma_2 * self.mlp_imag(self.norm2_imag(i))
+            return torch.cat([t, i], dim=1)
+        return x + self.gamma_2 * self.mlp_vl(self.norm2_vl(x))
+
+
+class FrozenVlmo(nn.Module):
+    """White box (pre-trained role) and, with ``vqa_head=True``, the black-box VQA scorer (fine-tuned role)."""
+
+    def __init__(self, cfg, seed=0, vqa_head=False):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.dim
+        self.word_embeddings = nn.Embedding(cfg.vocab, d)
+        self.position_embeddings = nn.Embedding(cfg.max_position, d)
+        self.bert_type_embeddings = nn.Embedding(2, d)
+        self.bert_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+        self.token_type_embeddings = nn.Embedding(2, d)
+        self.patch_proj = nn.Linear(3 * cfg.patch * cfg.patch, d)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, d))
+        self.blocks = nn.ModuleList([Block(cfg, i >= cfg.vlffn_start) for i in range(cfg.depth)])
+        self.norm = nn.LayerNorm(d, eps=cfg.ln_eps)
+        self.pooler = nn.Linear(d, d)
+        self.mlm_dense = nn.Linear(d, d)
+        self.mlm_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+        self.mlm_bias = nn.Parameter(torch.zeros(cfg.vocab))
+        ntok = cfg.max_text_len + cfg.n_image_tokens
+        # relative position bias, one (heads, T+N, T+N) slab per layer (vlmo_module.py:807-814); frozen -> precomputed
+        self.register_buffer("rel_pos_bias", torch.zeros(cfg.depth, cfg.heads, ntok, ntok), persistent=False)
+        self.vqa_classifier = None
+        if vqa_head:
+            self.vqa_classifier = nn.Sequential(nn.Linear(d, 2 * d), nn.LayerNorm(2 * d), nn.GELU(),
+                                                nn.Linear(2 * d, cfg.n_answers))
+        self._init(seed)
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def _init(self, seed):
+        g = torch.Generator().manual_seed(seed)
+
+        def normal_(t):
+            t.copy_(torch.empty(t.shape).normal_(0.0, 0.02, generator=g))
+
+        with torch.no_grad():
+            for mod in self.modules():
+                if isinstance(mod, (nn.Linear, nn.Embedding)):
+                    normal_(mod.weight)
+                    if getattr(mod, "bias", None) is not None:
+                        mod.bias.zero_()
+                elif isinstance(mod, nn.LayerNorm):
+                    mod.weight.fill_(1.0)
+                    mod.bias.zero_()
+            normal_(self.cls_token)
+            normal_(self.mlm_bias)
+            normal_(self.rel_pos_bias)
+
+    # ---- embeddings -----------------------------------------------------------------------------------------
+    def text_embeddings(self, ids):
+        """BERT embeddings (word + type 0, then + position, LayerNorm); eval mode -> no dropout."""
+        length = ids.shape[1]
+        e = self.word_embeddings(ids) + self.bert_type_embeddings.weight[0]
+        e = e + self.position_embeddings.weight[:length].unsqueeze(0)
+        return self.bert_ln(e)
+
+    def embedding_tables(self):
+        """Raw tables for the candidate-scoring kernel (``ops.cand_dir_sim``)."""
+        return dict(word=self.word_embeddings.weight, pos=self.position_embeddings.weight,
+                    type_emb=self.bert_type_embeddings.weight, gamma=self.bert_ln.weight, beta=self.bert_ln.bias,
+                    ln_eps=self.cfg.bert_ln_eps)
+
+    def visual_embed(self, image):
+        b, p = image.shape[0], self.cfg.patch
+        g = self.cfg.image_size // p
+        patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+        x = self.patch_proj(patches)
+        return torch.cat([self.cls_token.expand(b, -1, -1), x], dim=1)
+
+    # ---- trunk ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def attention_bias(self, text_masks):
+        """Per-layer additive attention masks ``(B, heads, S, S)`` = relative-position bias + key padding (-inf on
+        padded text keys).  They depend only on the text batch, so an attack builds them ONCE per text batch and
+        reuses them for every PGD step (HBM is 288 GB: 12 x 1.17 GB at batch 64 is cheap next to re-adding the two
+        terms 2 x depth times per step)."""
+        b = text_masks.shape[0]
+        keep = torch.cat([text_masks.bool(), torch.ones(b, self.cfg.n_image_tokens, dtype=torch.bool,
+                                                        device=text_masks.device)], dim=1)
+        pad = torch.zeros(b, 1, 1, keep.shape[1], device=text_masks.device).masked_fill(~keep[:, None, None, :],
+                                                                                       float("-inf"))
+        return [pad + self.rel_pos_bias[li].unsqueeze(0) for li in range(self.cfg.depth)]
+
+    def encode(self, image, text_embeds, text_masks, bias=None):
+        """Returns (per-layer inputs/outputs list of depth+1 tensors (B, T+N, D), final normed states)."""
+        t = text_embeds + self.token_type_embeddings.weight[0]
+        i = self.visual_embed(image) + self.token_type_embeddings.weight[1]
+        x = torch.cat([t, i], dim=1)
+        if bias is None:
+            bias = self.attention_bias(text_masks)
+        feats = [x]
+        for li, blk in enumerate(self.blocks):
+            x = blk(x, bias[li])
+            feats.append(x)
+        return feats, self.norm(x)
+
+    def mlm_score(self, text_states):
+        h = self.mlm_ln(F.gelu(self.mlm_dense(text_states)))
+        return F.linear(h, self.word_embeddings.weight, self.mlm_bias)
+
+    def pooled(self, states):
+        return torch.tanh(self.pooler(states[:, 0]))
+
+    @torch.no_grad()
+    def vqa_answer(self, image, text_ids, text_masks):
+        """Black-box prediction: argmax over the answer vocabulary (objectives.vqa_test_step_after_pgd, :812-829)."""
+        if self.vqa_classifier is None:
+            raise RuntimeError("this FrozenVlmo was built without a VQA head")
+        _, states = self.encode(image, self.text_embeddings(text_ids), text_masks)
+        return self.vqa_classifier(self.pooled(states)).argmax(dim=-1)
+
+
+class VlmoAttackAdapters:
+    """Batched ``model_fn`` closures over the current text batch (the reference's ``self.batch``)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.batch = {}
+
+    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
+        self.batch["text_ids"], self.batch["text_masks"] = text_ids, text_masks
+        self.batch["text_ids_mlm"] = text_ids if text_ids_mlm is None else text_ids_mlm
+        self.batch["text_mask_mlm"] = text_masks if text_mask_mlm is None else text_mask_mlm
+        self._weight = None
+        self._bias = self.model.attention_bias(text_masks)
+        self._bias_mlm = self._bias if text_mask_mlm is None else self.model.attention_bias(text_mask_mlm)
+
+    def text_embeddings(self, ids):
+        return self.model.text_embeddings(ids)
+
+    def mlm_logits(self, text_ids, text_masks):
+        """Candidate proposer stand-in for the reference's separate HF BERT-MLM (adv_attack.py:110,242): the white
+        box's own MLM head on a blank image-free pass is not available in VLMo, so use the text-only trunk."""
+        m = self.model
+        with torch.no_grad():
+            zeros = torch.zeros(text_ids.shape[0], 3, m.cfg.image_size, m.cfg.image_size, device=text_ids.device)
+            _, states = m.encode(zeros, m.text_embeddings(text_ids), text_masks)
+            return m.mlm_score(states[:, :text_ids.shape[1]])
+
+    def row_weight(self):
+        """uint8 (B, T+N): 2 for the [CLS] row (counted alone and as a token by the VLMO loss), 1 for real text tokens
+        and all image tokens, 0 for padded text tokens."""
+        if self._weight is None:
+            m = self.batch["text_masks"]
+            w = torch.cat([m.to(torch.uint8), torch.ones(m.shape[0], self.model.cfg.n_image_tokens, dtype=torch.uint8,
+                                                         device=m.device)], dim=1)
+            w[:, 0] = 2
+            self._weight = w.contiguous()
+        return self._weight
+
+    def _pack(self, feats, states):
+        return [self.model.pooled(states), None, LayerFeatures(feats, self.row_weight())]
+
+    def gen_ori_feats(self, image):
+        """Targets of the feature loss from the clean pair (``Gen_ori_feats``, vlmo_module.py:1287-1312)."""
+        with torch.no_grad():
+            m = self.model
+            feats, states = m.encode(image, m.text_embeddings(self.batch["text_ids"]), self.batch["text_masks"],
+                                     self._bias)
+        return [m.pooled(states), None, LayerFeatures(feats, self.row_weight())]
+
+    def pgd_attack(self, x):
+        m = self.model
+        feats, states = m.encode(x, m.text_embeddings(self.batch["text_ids"]), self.batch["text_masks"], self._bias)
+        return self._pack(feats, states)
+
+    def pgd_attack_vl(self, xs):
+        feats, states = self.model.encode(xs[0], xs[1], self.batch["text_masks"], self._bias)
+        return self._pack(feats, states)
+
+    def pgd_mlm_attack(self, x):
+        m = self.model
+        feats, states = m.encode(x, m.text_embeddings(self.batch["text_ids_mlm"]), self.batch["text_mask_mlm"],
+                                 self._bias_mlm)
+        logits = m.mlm_score(states[:, :m.cfg.max_text_len])
+        return [logits, None, LayerFeatures(feats, self.row_weight())]
