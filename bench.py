@@ -49,6 +49,7 @@ def parse():
 def synthetic_questions(batch, length, n_body, seed, device):
     """[CLS] + body ids U{1000..30521} + [SEP] + padding."""
     g = torch.Generator().manual_seed(seed)
+    n_body = max(1, min(n_body, length - 2))
     ids = torch.zeros(batch, length, dtype=torch.long)
     ids[:, 0] = 101
     ids[:, 1:1 + n_body] = torch.randint(1000, 30522, (batch, n_body), generator=g)
@@ -128,14 +129,33 @@ def step_kernel_microbench(batch, image_size, reps=40):
                 algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps))
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU box gives a
+    one-GPU job a 16-core share of a much larger host; oversubscribing torch's thread pool stalls it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("VQA_CPU_BASELINE_CORES", "16"))))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(args, cfg):
     """The reference's CPU path (oracle restatement + reference-style batch-1 packing) on the host cores."""
     import numpy as np
     from oracle import cleverhans_cpu as oracle
     from oracle.adapters_ref import VlmoRefAdapters
     from vqattack_amd.whitebox.vlmo import FrozenVlmo
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log("cpu_baseline: {} threads, {} of {} PGD steps on 1 image".format(cores, args.cpu_baseline_steps,
+                                                                         args.pgd_steps))
     model = FrozenVlmo(cfg, seed=0)
     ids, masks = synthetic_questions(1, cfg.max_text_len, 8, seed=0, device="cpu")
     g = torch.Generator().manual_seed(0)
@@ -198,8 +218,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         one_step()
+        torch.cuda.synchronize()
+        log("warmup step {} done".format(i))
     ledger.reset()
     timer = StepKernelTimer()
     timer.install()
@@ -216,6 +238,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     roof = timer.summary()
+    if rank == 0:
+        log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 
     if rank == 0:
         total = world * args.batch * args.steps

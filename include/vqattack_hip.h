@@ -39,7 +39,7 @@ const char* vqa_error_string(int code);
 
 /* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
  *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
- *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1) */
+ *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 3) */
 int vqa_set_option(int option, int value);
 
 /* ---------------------------------------------------------------- L-infinity image update (hot)

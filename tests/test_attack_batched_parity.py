@@ -1,0 +1,90 @@
+"""Batched joint attack on the MI355X vs the per-sample (batch 1, reference-style packing) CPU oracle.
+
+Same frozen white box (seeded weights) on both sides; the product attacks a batch of 3 questions with different
+padding in one go (LayerFeatures + row weights, no packing), the oracle attacks them one at a time the way the
+reference does.  Tolerances: >= 99 % of the pixels bit-identical per sample (sign flips of ~0 gradients aside, every
+step moves a pixel by exactly +-eps_iter), substituted token ids identical, summed per-sample losses within 2e-4
+relative of the batch loss.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attack_loop
+from oracle.adapters_ref import AlbefRefAdapters, VlmoRefAdapters
+from vqattack_amd.attack import text_update
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+IDS = torch.tensor([[101, 2054, 3609, 2003, 102, 0, 0, 0],
+                    [101, 2129, 2116, 6077, 2024, 102, 0, 0],
+                    [101, 2003, 2009, 102, 0, 0, 0, 0]])
+ATTACKABLE = torch.zeros_like(IDS, dtype=torch.bool)
+ATTACKABLE[0, [1, 2]] = True
+ATTACKABLE[1, [2, 4]] = True
+ATTACKABLE[2, [1, 2]] = True
+
+
+def _build(flavor):
+    if flavor == "vlmo":
+        from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny
+        cfg = vlmo_tiny()
+        return (FrozenVlmo(cfg, seed=3), FrozenVlmo(cfg, seed=3).to(DEV), VlmoAttackAdapters, VlmoRefAdapters, cfg)
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_tiny
+    cfg = albef_tiny(mlm_probability=0.0)      # the per-forward random token masking is exercised in test_albef_masking
+    return (FrozenAlbef(cfg, seed=3), FrozenAlbef(cfg, seed=3).to(DEV), AlbefAttackAdapters, AlbefRefAdapters, cfg)
+
+
+@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
+@pytest.mark.parametrize("with_words", [True, False])
+def test_batched_attack_matches_per_sample_oracle(flavor, with_words):
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    cpu_model, gpu_model, adapters_cls, ref_cls, cfg = _build(flavor)
+    g = torch.Generator().manual_seed(11)
+    images = torch.empty(3, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(images).uniform_(-0.125, 0.125, generator=g)
+    masks = (IDS != 0).long()
+    attackable = ATTACKABLE if with_words else torch.zeros_like(ATTACKABLE)
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(adapters_cls(gpu_model), flavor, gpu_model.embedding_tables(),
+                             AttackConfig(budget=10, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    # candidate proposals: computed once on the device, injected on both sides (host data)
+    proposals = None
+    if with_words:
+        logits = attack.adapters.mlm_logits(IDS.to(DEV), masks.to(DEV))
+        proposals = text_update.propose_candidates(logits, IDS, attackable, threshold=0)
+        assert all(len(p) == 2 for p in proposals)
+    res = attack.attack_batch(images.to(DEV), IDS.to(DEV), masks.to(DEV), attackable.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    assert res.gradient_steps == (10 + 2 if with_words else 10)
+    want_losses = None
+    for s in range(3):
+        adv, ids, losses = attack_loop.attack_one(ref_cls, cpu_model, flavor, images[s:s + 1], IDS[s:s + 1],
+                                                  masks[s:s + 1], proposals[s] if with_words else None, sim,
+                                                  init_eta=eta[s:s + 1], budget=10, sim_threshold=0.3)
+        same = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
+        assert same >= 0.99, (flavor, s, same)
+        assert float((res.adv_images[s].cpu() - images[s]).abs().max()) <= np.float32(0.125) + 1e-7
+        assert res.adv_text_ids[s].cpu().tolist() == ids[0].tolist(), (flavor, s)
+        flat = np.array([v for block in losses for v in block])
+        want_losses = flat if want_losses is None else want_losses + flat
+    got_losses = np.array([v for block in res.loss_lists for v in block])
+    assert np.allclose(got_losses, want_losses, rtol=2e-4, atol=1e-5), (got_losses, want_losses)
+    if with_words:
+        changed = (res.adv_text_ids.cpu() != IDS).sum().item()
+        assert changed >= 1, "the test is meant to exercise at least one accepted substitution"
+
+
+def test_albef_masking_is_reproducible_and_respects_specials():
+    from vqattack_amd.whitebox.albef import FrozenAlbef, albef_tiny
+    m = FrozenAlbef(albef_tiny(mlm_probability=0.5), seed=0)
+    ids = IDS.clone()
+    m.seed_masking(7)
+    a = m.mask_tokens(ids)
+    m.seed_masking(7)
+    b = m.mask_tokens(ids)
+    assert torch.equal(a, b) and not torch.equal(a, ids)
+    assert torch.equal(a[:, 0], ids[:, 0])                       # [CLS] never masked
+    assert torch.equal(a[ids == 0], ids[ids == 0])               # padding never masked
+    assert torch.equal(ids, IDS)                                 # input untouched

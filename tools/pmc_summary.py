@@ -1,0 +1,33 @@
+"""Summarise rocprofv3 --pmc counter_collection.csv files for the vqa:: kernels.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-byte read requests at 64 B,
+i.e. exactly half of a wide coalesced stream (MI355X_MICROARCH.md, HBM section), so it is doubled here.
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv>
+"""
+import csv
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def load(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or "vqa::" not in r["Kernel_Name"]:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[(name, int(r["Grid_Size"]))].append((float(r["Counter_Value"]),
+                                                  int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return acc
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+for key in sorted(fetch):
+    f = sum(v for v, _ in fetch[key]) / len(fetch[key])
+    w = sum(v for v, _ in write.get(key, [(0, 0)])) / max(len(write.get(key, [])), 1)
+    dur = sum(d for _, d in fetch[key]) / len(fetch[key])
+    fetch_b, write_b = 2 * f * 1024, w * 1024
+    print("%-58s grid %9d  launches %d  FETCH_SIZE %.0f KiB (x2 -> %.1f MB)  WRITE_SIZE %.0f KiB (%.1f MB)  "
+          "HBM traffic %.1f MB  dur(profiled) %.1f us" % (key[0][:58], key[1], len(fetch[key]), f, fetch_b / 1e6, w,
+                                                         write_b / 1e6, (fetch_b + write_b) / 1e6, dur / 1e3))

@@ -36,6 +36,7 @@ class AttackConfig:
     norm: float = np.inf
     random_start: bool = True          # first block uses time=0 (uniform start), like the reference
     sanity_checks: bool = False        # the flag read is a host sync; parity tests switch it on
+    sim_threshold: float = text_update.SIM_THRESHOLD   # adv_attack.py:303
 
 
 @dataclass
@@ -83,12 +84,13 @@ class BatchedVQAttack:
 
     @torch.no_grad()
     def attack_batch(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, dual=False,
-                     mlm_labels=None, init_eta=None):
+                     mlm_labels=None, init_eta=None, proposals=None):
         """Attack one batch whose samples all have the same number of attackable words.
 
         images (B,3,H,W) in [clip_min, clip_max]; text_ids/text_masks (B,L); attackable bool (B,L) with the same
         count per row.  ``mlm_logits_fn(text_ids, text_masks) -> (B,L,V)`` proposes substitution candidates (the
-        reference uses a separate HF BERT-MLM, adv_attack.py:110,242).  Returns a ``BatchResult``.
+        reference uses a separate HF BERT-MLM, adv_attack.py:110,242; default: the adapters' own ``mlm_logits``);
+        ``proposals`` injects them directly (``text_update.propose_candidates`` format).  Returns a ``BatchResult``.
         """
         c, a = self.cfg, self.adapters
         n_words = int(attackable[0].sum().item())
@@ -107,10 +109,11 @@ class BatchedVQAttack:
             res.loss_lists.append(losses)
             res.gradient_steps = c.budget
         else:
-            proposals = None
-            if mlm_logits_fn is not None:
-                proposals = text_update.propose_candidates(mlm_logits_fn(text_ids, text_masks), text_ids, attackable,
-                                                           banned=self.banned_ids)
+            if proposals is None:
+                fn = mlm_logits_fn or getattr(a, "mlm_logits", None)
+                if fn is not None:
+                    proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
+                                                               banned=self.banned_ids)
             e_ori = a.text_embeddings(text_ids)
             ori_host = text_ids.cpu().numpy()
             positions = list(range(text_ids.shape[1]))
@@ -132,7 +135,7 @@ class BatchedVQAttack:
                 if proposals is not None:
                     cand, scores = text_update.score_candidates(self.tables, e_ori, text_grad, proposals)
                     new_ids, subs = text_update.greedy_accept(cand, scores, ori_host, adv_ids.cpu().numpy(),
-                                                              self.similarity_fn)
+                                                              self.similarity_fn, c.sim_threshold)
                     adv_ids = torch.as_tensor(new_ids, device=text_ids.device, dtype=text_ids.dtype)
                     res.substitutions.append(subs)
         res.adv_images, res.adv_text_ids = adv, adv_ids

@@ -1,0 +1,291 @@
+"""Frozen ALBEF-shaped white box (ViT-B/16 + BERT with cross-attention fusion) and its batched attack adapters.
+
+Shapes follow the reference: ``ALBEF_attack/models/vit.py`` (``VisionTransformer.forward`` :160-177 returns the final
+states and the 13 per-layer maps), ``models/xbert.py`` (``BertEmbeddings`` :169-216; 12 BERT layers, cross-attention to
+the image states in layers >= ``fusion_layer`` = 6; 13 hidden states; MLM head) and ``models/model_pretrain.py``
+(``Gen_feats`` :124-141, ``Gen_feats_from_embeds`` :85-104, ``get_mlm_logits`` :105-122, the random 15 % token masking
+``mask`` :309-332 applied inside every white-box forward).  Weights are random (seeded) and frozen.
+
+PyTorch-ROCm plumbing, not the product: the product is what happens between two calls of these closures.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..features import LayerFeatures
+
+
+@dataclass
+class AlbefConfig:
+    dim: int = 768
+    vit_depth: int = 12
+    bert_depth: int = 12
+    fusion_layer: int = 6
+    heads: int = 12
+    patch: int = 16
+    image_size: int = 384
+    vocab: int = 30522
+    max_position: int = 512
+    n_answers: int = 3128
+    mlm_probability: float = 0.15     # configs/Pretrain.yaml
+    pad_id: int = 0
+    cls_id: int = 101
+    mask_id: int = 103
+    vit_ln_eps: float = 1e-6
+    bert_ln_eps: float = 1e-12
+
+    @property
+    def n_image_tokens(self):
+        return (self.image_size // self.patch) ** 2 + 1
+
+
+def albef_base(image_size=384, **kw):
+    return AlbefConfig(image_size=image_size, **kw)
+
+
+def albef_tiny(**kw):
+    return AlbefConfig(dim=64, vit_depth=2, bert_depth=4, fusion_layer=2, heads=4, patch=8, image_size=32,
+                       n_answers=13, **kw)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _MHA(nn.Module):
+    """Multi-head attention with separate q / kv inputs (self- or cross-attention)."""
+
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+
+    def forward(self, x, ctx, mask=None):
+        b, n, c = x.shape
+        m = ctx.shape[1]
+        h = self.heads
+        q = self.q(x).reshape(b, n, h, c // h).transpose(1, 2)
+        k = self.k(ctx).reshape(b, m, h, c // h).transpose(1, 2)
+        v = self.v(ctx).reshape(b, m, h, c // h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.o(o.transpose(1, 2).reshape(b, n, c))
+
+
+class _VitBlock(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(cfg.dim, eps=cfg.vit_ln_eps)
+        self.attn = _MHA(cfg.dim, cfg.heads)
+        self.norm2 = nn.LayerNorm(cfg.dim, eps=cfg.vit_ln_eps)
+        self.mlp = _Mlp(cfg.dim, 4 * cfg.dim)
+
+    def forward(self, x):
+        h = self.norm1(x)
+        x = x + self.attn(h, h)
+        return x + self.mlp(self.norm2(x))
+
+
+class _BertLayer(nn.Module):
+    """Post-LN BERT layer, optionally with cross-attention to the image states (xbert.py BertLayer)."""
+
+    def __init__(self, cfg, cross):
+        super().__init__()
+        d, e = cfg.dim, cfg.bert_ln_eps
+        self.attn, self.ln_attn = _MHA(d, cfg.heads), nn.LayerNorm(d, eps=e)
+        self.cross = _MHA(d, cfg.heads) if cross else None
+        self.ln_cross = nn.LayerNorm(d, eps=e) if cross else None
+        self.mlp, self.ln_out = _Mlp(d, 4 * d), nn.LayerNorm(d, eps=e)
+
+    def forward(self, x, self_mask, image_states):
+        x = self.ln_attn(x + self.attn(x, x, self_mask))
+        if self.cross is not None:
+            x = self.ln_cross(x + self.cross(x, image_states))
+        return self.ln_out(x + self.mlp(x))
+
+
+class FrozenAlbef(nn.Module):
+    def __init__(self, cfg, seed=0, vqa_head=False):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.dim
+        self.patch_proj = nn.Linear(3 * cfg.patch * cfg.patch, d)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, d))
+        self.pos_embed = nn.Parameter(torch.zeros(1, cfg.n_image_tokens, d))
+        self.vit_blocks = nn.ModuleList([_VitBlock(cfg) for _ in range(cfg.vit_depth)])
+        self.vit_norm = nn.LayerNorm(d, eps=cfg.vit_ln_eps)
+        self.word_embeddings = nn.Embedding(cfg.vocab, d)
+        self.position_embeddings = nn.Embedding(cfg.max_position, d)
+        self.type_embeddings = nn.Embedding(2, d)
+        self.emb_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+        self.bert_layers = nn.ModuleList([_BertLayer(cfg, i >= cfg.fusion_layer) for i in range(cfg.bert_depth)])
+        self.mlm_dense = nn.Linear(d, d)
+        self.mlm_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+        self.mlm_bias = nn.Parameter(torch.zeros(cfg.vocab))
+        self.vqa_classifier = nn.Sequential(nn.Linear(d, 2 * d), nn.GELU(), nn.Linear(2 * d, cfg.n_answers)) \
+            if vqa_head else None
+        self._mask_gen = None
+        self._init(seed)
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def _init(self, seed):
+        g = torch.Generator().manual_seed(seed)
+
+        def normal_(t):
+            t.copy_(torch.empty(t.shape).normal_(0.0, 0.02, generator=g))
+
+        with torch.no_grad():
+            for mod in self.modules():
+                if isinstance(mod, (nn.Linear, nn.Embedding)):
+                    normal_(mod.weight)
+                    if getattr(mod, "bias", None) is not None:
+                        mod.bias.zero_()
+                elif isinstance(mod, nn.LayerNorm):
+                    mod.weight.fill_(1.0)
+                    mod.bias.zero_()
+            normal_(self.cls_token)
+            normal_(self.pos_embed)
+            normal_(self.mlm_bias)
+
+    # ---- pieces ---------------------------------------------------------------------------------------------
+    def visual_encoder(self, image):
+        b, p = image.shape[0], self.cfg.patch
+        g = self.cfg.image_size // p
+        patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+        x = torch.cat([self.cls_token.expand(b, -1, -1), self.patch_proj(patches)], dim=1) + self.pos_embed
+        feats = [x]
+        for blk in self.vit_blocks:
+            x = blk(x)
+            feats.append(x)
+        return self.vit_norm(x), feats
+
+    def text_embeddings(self, ids):
+        length = ids.shape[1]
+        e = self.word_embeddings(ids) + self.type_embeddings.weight[0]
+        e = e + self.position_embeddings.weight[:length].unsqueeze(0)
+        return self.emb_ln(e)
+
+    def embedding_tables(self):
+        return dict(word=self.word_embeddings.weight, pos=self.position_embeddings.weight,
+                    type_emb=self.type_embeddings.weight, gamma=self.emb_ln.weight, beta=self.emb_ln.bias,
+                    ln_eps=self.cfg.bert_ln_eps)
+
+    def seed_masking(self, seed):
+        """Make the per-forward random MLM masking reproducible (None -> torch's global generator)."""
+        self._mask_gen = None if seed is None else seed
+
+    def mask_tokens(self, ids):
+        """The reference's ``mask`` (model_pretrain.py:309-332) on a copy of ``ids``: 15 % of the non-[CLS], non-pad
+        tokens are selected; 80 % of those become [MASK], 10 % a random word, 10 % stay."""
+        c = self.cfg
+        if c.mlm_probability <= 0:
+            return ids
+        gen = None
+        if self._mask_gen is not None:
+            gen = torch.Generator().manual_seed(self._mask_gen)
+            self._mask_gen += 1
+        ids_cpu = ids.cpu().clone()
+        sel = torch.bernoulli(torch.full(ids_cpu.shape, c.mlm_probability), generator=gen).bool()
+        sel &= (ids_cpu != c.pad_id) & (ids_cpu != c.cls_id)
+        rep = torch.bernoulli(torch.full(ids_cpu.shape, 0.8), generator=gen).bool() & sel
+        ids_cpu[rep] = c.mask_id
+        rnd = torch.bernoulli(torch.full(ids_cpu.shape, 0.5), generator=gen).bool() & sel & ~rep
+        words = torch.randint(c.vocab, ids_cpu.shape, generator=gen)
+        ids_cpu[rnd] = words[rnd]
+        return ids_cpu.to(ids.device)
+
+    def text_encoder(self, text_embeds, text_masks, image_states):
+        pad = torch.zeros(text_masks.shape[0], 1, 1, text_masks.shape[1], device=text_embeds.device)
+        pad = pad.masked_fill(~text_masks.bool()[:, None, None, :], float("-inf"))
+        x = text_embeds
+        feats = [x]
+        for layer in self.bert_layers:
+            x = layer(x, pad, image_states)
+            feats.append(x)
+        return x, feats
+
+    def mlm_head(self, states):
+        h = self.mlm_ln(F.gelu(self.mlm_dense(states)))
+        return F.linear(h, self.word_embeddings.weight, self.mlm_bias)
+
+    # ---- the three entry points the reference's adapters call -------------------------------------------------
+    def gen_feats(self, image, text_ids, text_masks):
+        image_states, img_feats = self.visual_encoder(image)
+        emb = self.text_embeddings(self.mask_tokens(text_ids))
+        _, txt_feats = self.text_encoder(emb, text_masks, image_states)
+        return img_feats, txt_feats
+
+    def gen_feats_from_embeds(self, image, text_embeds, text_ids, text_masks):
+        image_states, img_feats = self.visual_encoder(image)
+        self.mask_tokens(text_ids)            # the reference draws (and then ignores) a mask here too
+        _, txt_feats = self.text_encoder(text_embeds, text_masks, image_states)
+        return img_feats, txt_feats
+
+    def get_mlm_logits(self, image, text_ids, text_masks):
+        image_states, _ = self.visual_encoder(image)
+        states, _ = self.text_encoder(self.text_embeddings(self.mask_tokens(text_ids)), text_masks, image_states)
+        return self.mlm_head(states)
+
+    @torch.no_grad()
+    def vqa_answer(self, image, text_ids, text_masks):
+        """Black-box stand-in: answer = argmax of a classifier on the fused [CLS] state.  (The reference's black box
+        ranks 128 candidate answers with a text decoder, models/model_vqa.py:149-203 -- a 'next' row)"""
+        if self.vqa_classifier is None:
+            raise RuntimeError("this FrozenAlbef was built without a VQA head")
+        image_states, _ = self.visual_encoder(image)
+        states, _ = self.text_encoder(self.text_embeddings(text_ids), text_masks, image_states)
+        return self.vqa_classifier(states[:, 0]).argmax(dim=-1)
+
+
+class AlbefAttackAdapters:
+    """Batched closures over the current text batch; outputs are ``[txt, img]`` like ``Adv_attack.pgd_attack``."""
+
+    def __init__(self, model):
+        self.model = model
+        self.batch = {}
+
+    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
+        self.batch["text_ids"], self.batch["text_masks"] = text_ids, text_masks
+        self.batch["text_ids_mlm"] = text_ids if text_ids_mlm is None else text_ids_mlm
+        self.batch["text_mask_mlm"] = text_masks if text_mask_mlm is None else text_mask_mlm
+        self._weight = text_masks.to(torch.uint8).contiguous()   # padded text tokens carry no loss (batch-1 parity)
+
+    def text_embeddings(self, ids):
+        return self.model.text_embeddings(ids)
+
+    def mlm_logits(self, text_ids, text_masks):
+        m = self.model
+        with torch.no_grad():
+            pad = torch.zeros(text_ids.shape[0], 1, 1, text_ids.shape[1], device=text_ids.device)
+            pad = pad.masked_fill(~text_masks.bool()[:, None, None, :], float("-inf"))
+            x = m.text_embeddings(text_ids)
+            for layer in m.bert_layers[:m.cfg.fusion_layer]:      # text-only trunk as the candidate proposer
+                x = layer(x, pad, None)
+            return m.mlm_head(x)
+
+    def _pack(self, img_feats, txt_feats):
+        return [LayerFeatures(txt_feats, self._weight), LayerFeatures(img_feats)]
+
+    def gen_ori_feats(self, image):
+        with torch.no_grad():
+            img, txt = self.model.gen_feats(image, self.batch["text_ids"], self.batch["text_masks"])
+        return self._pack(img, txt)
+
+    def pgd_attack(self, x):
+        img, txt = self.model.gen_feats(x, self.batch["text_ids"], self.batch["text_masks"])
+        return self._pack(img, txt)
+
+    def pgd_attack_vl(self, xs):
+        img, txt = self.model.gen_feats_from_embeds(xs[0], xs[1], self.batch["text_ids"], self.batch["text_masks"])
+        return self._pack(img, txt)
+
+    def pgd_mlm_attack(self, x):
+        return [self.model.get_mlm_logits(x, self.batch["text_ids_mlm"], self.batch["text_mask_mlm"])]

@@ -105,13 +105,13 @@ class Block(nn.Module):
         self.max_text_len = cfg.max_text_len
 
     def forward(self, x, bias):
-        x = x + self.gamma_1 * self.attn(self.norm1(x), bias)
+        x = torch.addcmul(x, self.gamma_1, self.attn(self.norm1(x), bias))
         if self.mlp_vl is None:     # modality experts: text tokens / image tokens (multiway_transformer.py:193-197)
             t, i = x[:, :self.max_text_len], x[:, self.max_text_len:]
-            t = t + self.gamma_2 * self.mlp_text(self.norm2_text(t))
-            i = i + self.gamma_2 * self.mlp_imag(self.norm2_imag(i))
+            t = torch.addcmul(t, self.gamma_2, self.mlp_text(self.norm2_text(t)))
+            i = torch.addcmul(i, self.gamma_2, self.mlp_imag(self.norm2_imag(i)))
             return torch.cat([t, i], dim=1)
-        return x + self.gamma_2 * self.mlp_vl(self.norm2_vl(x))
+        return torch.addcmul(x, self.gamma_2, self.mlp_vl(self.norm2_vl(x)))
 
 
 class FrozenVlmo(nn.Module):
@@ -189,16 +189,33 @@ class FrozenVlmo(nn.Module):
     # ---- trunk ----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def attention_bias(self, text_masks):
-        """Per-layer additive attention masks ``(B, heads, S, S)`` = relative-position bias + key padding (-inf on
-        padded text keys).  They depend only on the text batch, so an attack builds them ONCE per text batch and
-        reuses them for every PGD step (HBM is 288 GB: 12 x 1.17 GB at batch 64 is cheap next to re-adding the two
-        terms 2 x depth times per step)."""
+        """Per-layer additive attention masks = relative-position bias + key padding (-inf on padded text keys).
+
+        They depend only on the text batch, so an attack builds them ONCE per text batch and reuses them for every PGD
+        step.  Layout choices that keep the fused attention kernel off the HBM roof:
+          * rows are padded to a multiple of 16 floats in storage and sliced back, so SDPA's alignment check passes
+            and it does not re-pad (= copy) the whole mask on every call;
+          * when every question of the batch has the same padding pattern (batches are bucketed by schedule and
+            length) the mask is ONE (1, heads, S, S) slab expanded over the batch with stride 0: 18 MB per layer that
+            stays cache-resident instead of a (B, heads, S, S) tensor (1.17 GB at batch 64) streamed by every
+            forward and backward attention kernel.  Otherwise it is materialised per sample (HBM is 288 GB).
+        """
         b = text_masks.shape[0]
+        s = self.cfg.max_text_len + self.cfg.n_image_tokens
+        s_pad = (s + 15) // 16 * 16
         keep = torch.cat([text_masks.bool(), torch.ones(b, self.cfg.n_image_tokens, dtype=torch.bool,
                                                         device=text_masks.device)], dim=1)
-        pad = torch.zeros(b, 1, 1, keep.shape[1], device=text_masks.device).masked_fill(~keep[:, None, None, :],
+        shared = bool((keep == keep[:1]).all())          # one host sync per text batch
+        rows = keep[:1] if shared else keep
+        pad = torch.zeros(rows.shape[0], 1, 1, s, device=text_masks.device).masked_fill(~rows[:, None, None, :],
                                                                                        float("-inf"))
-        return [pad + self.rel_pos_bias[li].unsqueeze(0) for li in range(self.cfg.depth)]
+        out = []
+        for li in range(self.cfg.depth):
+            store = torch.zeros(rows.shape[0], self.cfg.heads, s, s_pad, device=text_masks.device)
+            store[..., :s] = pad + self.rel_pos_bias[li].unsqueeze(0)
+            view = store[..., :s]
+            out.append(view.expand(b, -1, -1, -1) if shared else view)
+        return out
 
     def encode(self, image, text_embeds, text_masks, bias=None):
         """Returns (per-layer inputs/outputs list of depth+1 tensors (B, T+N, D), final normed states)."""
