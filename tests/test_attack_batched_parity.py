@@ -60,13 +60,17 @@ def test_batched_attack_matches_per_sample_oracle(flavor, with_words):
     assert res.gradient_steps == (10 + 2 if with_words else 10)
     want_losses = None
     for s in range(3):
-        adv, ids, losses = attack_loop.attack_one(ref_cls, cpu_model, flavor, images[s:s + 1], IDS[s:s + 1],
-                                                  masks[s:s + 1], proposals[s] if with_words else None, sim,
+        # ALBEF at batch 1 tokenises with padding='longest', i.e. WITHOUT pad tokens (adv_attack.py:113); VLMo pads every
+        # question to max_text_len and drops the padded rows through the mask (vlmo_module.py:1440-1442)
+        n = int(masks[s].sum()) if flavor == "albef" else IDS.shape[1]
+        adv, ids, losses = attack_loop.attack_one(ref_cls, cpu_model, flavor, images[s:s + 1], IDS[s:s + 1, :n],
+                                                  masks[s:s + 1, :n], proposals[s] if with_words else None, sim,
                                                   init_eta=eta[s:s + 1], budget=10, sim_threshold=0.3)
         same = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
         assert same >= 0.99, (flavor, s, same)
         assert float((res.adv_images[s].cpu() - images[s]).abs().max()) <= np.float32(0.125) + 1e-7
-        assert res.adv_text_ids[s].cpu().tolist() == ids[0].tolist(), (flavor, s)
+        assert res.adv_text_ids[s, :n].cpu().tolist() == ids[0].tolist(), (flavor, s)
+        assert res.adv_text_ids[s, n:].cpu().tolist() == IDS[s, n:].tolist()
         flat = np.array([v for block in losses for v in block])
         want_losses = flat if want_losses is None else want_losses + flat
     got_losses = np.array([v for block in res.loss_lists for v in block])

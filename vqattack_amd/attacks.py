@@ -133,14 +133,20 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra_los
             raise HipExtensionError("model_fn outputs and targets y must be on the HIP device")
         o32 = o if o.dtype == torch.float32 else o.to(torch.float32)
         t32 = t.detach() if t.dtype == torch.float32 else t.detach().to(torch.float32)
-        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=True,
+        # layers that do not depend on a leaf (ALBEF text states below the fusion layer during image-only steps)
+        # still contribute their constant to the loss value, but need no gradient pass
+        needs_grad = o32.requires_grad
+        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=needs_grad,
                               row_weight=w, weight_period=(o32.shape[0] if w is not None else 1))
-        tensors.append(o32)
-        grads.append(ga)
+        if needs_grad:
+            tensors.append(o32)
+            grads.append(ga)
     if extra_loss is not None:
         slot.word.add_(extra_loss.detach().to(torch.float32) * sign)
         tensors.append(extra_loss)
         grads.append(torch.full_like(extra_loss, float(sign)))
+    if not tensors:
+        raise RuntimeError("model_fn's outputs do not depend on the attacked input (nothing requires grad)")
     torch.autograd.backward(tensors, grads, inputs=leaves)
 
 

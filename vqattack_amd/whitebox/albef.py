@@ -46,7 +46,9 @@ def albef_base(image_size=384, **kw):
 
 
 def albef_tiny(**kw):
-    return AlbefConfig(dim=64, vit_depth=2, bert_depth=4, fusion_layer=2, heads=4, patch=8, image_size=32,
+    # vit_depth == bert_depth: the reference's loss adds the per-row sums of the two modalities elementwise
+    # (fast_gradient_method.py:127), which only works when both encoders return the same number of layers (13 / 13)
+    return AlbefConfig(dim=64, vit_depth=3, bert_depth=3, fusion_layer=1, heads=4, patch=8, image_size=32,
                        n_answers=13, **kw)
 
 
