@@ -1,0 +1,37 @@
+"""Shared plumbing of the two reference-style entry points."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def init_distributed():
+    """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the launcher (torchrun).  Single process otherwise
+    -- like the reference's 'Not using distributed mode' (ALBEF_attack/utils.py:245-247)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("the attack path runs on MI355X GPUs only (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, torch.device("cuda", local)
+
+
+def finish(rank, world, result, out_json=None):
+    if rank == 0:
+        print("acc_vqa", result["asr"], result["n_total"], flush=True)     # the reference's final print (vlmo_module.py:2122)
+        if out_json:
+            with open(out_json, "w") as f:
+                json.dump(result["adv_text"], f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

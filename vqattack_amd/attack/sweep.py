@@ -1,0 +1,83 @@
+"""Sharded sweep over a (synthetic) question set: bucket by schedule -> batch -> attack -> score -> gather ASR.
+
+Mirrors what the reference's outer loops do one sample at a time (``Adv_attack.evaluate`` ``adv_attack.py:415-735``;
+``VLMo.test_step`` / ``test_epoch_end`` ``vlmo_module.py:1725-2124``): skip nothing, attack, keep the adversarial text,
+optionally save ``<qid>.pt`` (``adv_attack.py:714``), score with the black box, report the running attack accuracy.
+Offline there are no VQAv2 images, tokenizer or checkpoints, so samples are synthetic:
+images U(-1,1), questions ``[CLS] body [SEP] pad`` with 4..12 body tokens, all body tokens single-piece words.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from .asr import SuccessLedger, shard_indices
+from .runner import AttackConfig, BatchedVQAttack
+from .schedule import bucket_by_schedule, gradient_steps
+
+
+def synthetic_questions(n_samples, text_len, seed=0, min_words=4, max_words=12, joint=True):
+    """ids (n, L) int64, masks, attackable (n, L) bool -- on the host (tiny)."""
+    r = np.random.RandomState(seed)
+    ids = np.zeros((n_samples, text_len), dtype=np.int64)
+    att = np.zeros((n_samples, text_len), dtype=bool)
+    hi = min(max_words, text_len - 2)
+    for s in range(n_samples):
+        n = int(r.randint(min(min_words, hi), hi + 1))
+        ids[s, 0] = 101
+        ids[s, 1:1 + n] = r.randint(1000, 30522, n)
+        ids[s, 1 + n] = 102
+        if joint:
+            att[s, 1:1 + n] = True
+    return torch.from_numpy(ids), torch.from_numpy((ids != 0).astype(np.int64)), torch.from_numpy(att)
+
+
+def synthetic_images(qids, image_size, device):
+    out = torch.empty(len(qids), 3, image_size, image_size, device=device)
+    for i, q in enumerate(qids):
+        g = torch.Generator(device=device).manual_seed(1_000_003 * int(q) + 17)
+        out[i].uniform_(-1, 1, generator=g)
+    return out
+
+
+def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
+              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12):
+    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank."""
+    ids, masks, att = synthetic_questions(n_samples, text_len, seed=seed, joint=joint, max_words=max_words)
+    mine = shard_indices(n_samples, rank, world)
+    attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
+    ledger = SuccessLedger(world, rank, device)
+    buckets = bucket_by_schedule([int(att[i].sum()) for i in mine])
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+    adv_text = {}
+    steps = 0
+    done = 0
+    t0 = time.perf_counter()
+    for n_words, local in buckets.items():
+        for lo in range(0, len(local), batch):
+            qids = [mine[j] for j in local[lo:lo + batch]]
+            images = synthetic_images(qids, image_size, device)
+            tid, tmask, tatt = ids[qids].to(device), masks[qids].to(device), att[qids].to(device)
+            clean = black.vqa_answer(images, tid, tmask)
+            res = attack.attack_batch(images, tid, tmask, tatt)
+            after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
+            ledger.record(after != clean, sample_ids=qids)
+            steps += res.gradient_steps * len(qids)
+            assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget)
+            for q, row in zip(qids, res.adv_text_ids.cpu().tolist()):
+                adv_text[str(q)] = row
+            if save_dir:
+                for q, img in zip(qids, res.adv_images):
+                    torch.save(img[None].cpu().detach(), os.path.join(save_dir, "{}.pt".format(q)))
+            done += len(qids)
+            if rank == 0 and log_every and done % log_every < len(qids):
+                bits = ledger.local_bits()
+                print("attack_accuracy", float(bits.float().mean().item()), "({} local samples)".format(done),
+                      flush=True)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    asr = ledger.all_gather_rate()
+    return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,
+                examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text)
