@@ -64,43 +64,84 @@ def make_config(args):
     return getattr(vlmo, args.model)(image_size=args.image_size)
 
 
-class StepKernelTimer:
-    """HIP-event timing of every ``vqa_linf_step`` launch, on the stream the kernel is launched on."""
+# HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+# separate rocprofv3 runs, tools/pmc_step.py + tools/pmc_summary.py), keyed by elements per launch
+PMC_TRAFFIC_BYTES = {64 * 3 * 384 * 384: (165923 * 2 + 110592) * 1024, 256 * 3 * 384 * 384: (663589 * 2 + 442368) * 1024}
+
+
+class KernelTimer:
+    """HIP-event timing of every launch of two hand-written kernels, on the stream they are launched on:
+    ``vqa_linf_step`` (the fused sign+clamp+project step) and ``vqa_neg_cos_rows`` (fused cosine loss + gradient)."""
 
     def __init__(self):
-        self.events, self.numel = [], 0
+        self.step_events, self.step_numel = [], 0
+        self.loss_events, self.loss_bytes = [], 0
+        self._live = {}
 
     def install(self):
         from vqattack_amd import ops
-        self._orig = ops.linf_step
+        self._step, self._loss = ops.linf_step, ops.neg_cos_rows
         timer = self
 
-        def timed(x, *a, **kw):
+        def timed_step(x, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()                       # torch's current stream == the launch stream (ops.stream_for)
-            out = timer._orig(x, *a, **kw)
+            out = timer._step(x, *a, **kw)
             e1.record()
-            timer.events.append((e0, e1))
-            timer.numel = x.numel()
+            timer.step_events.append((e0, e1))
+            timer.step_numel = x.numel()
             return out
-        ops.linf_step = timed
+
+        def timed_loss(a_, b_, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._loss(a_, b_, *a, **kw)
+            e1.record()
+            timer.loss_events.append((e0, e1))
+            w = kw.get("row_weight")
+            rows = a_.numel() // a_.shape[-1]
+            if w is not None:                 # live (weight != 0) rows; one host read per distinct weight plane
+                key = (w.data_ptr(), w.numel())
+                if key not in timer._live:
+                    timer._live[key] = int((w != 0).sum().item())
+                rows = timer._live[key] * (rows // w.numel())
+            timer.loss_bytes = (12 if out is not None else 8) * rows * a_.shape[-1]
+            return out
+        ops.linf_step, ops.neg_cos_rows = timed_step, timed_loss
 
     def remove(self):
         from vqattack_amd import ops
-        ops.linf_step = self._orig
+        ops.linf_step, ops.neg_cos_rows = self._step, self._loss
+
+    @staticmethod
+    def _stats(events):
+        ms = [a.elapsed_time(b) for a, b in events]
+        return (sum(ms) / len(ms), min(ms), len(ms)) if ms else (None, None, 0)
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self.events]
-        if not ms:
-            return None
-        mean_ms = sum(ms) / len(ms)
-        nbytes = STEP_BYTES_PER_ELEM * self.numel
+        mean_ms, min_ms, n = self._stats(self.step_events)
+        if not n:
+            return None, None
+        nbytes = STEP_BYTES_PER_ELEM * self.step_numel
         gbs = nbytes / mean_ms / 1e6
-        return dict(kernel="vqa_linf_step (stream4_kernel<StepOp>)", bound="hbm", achieved=round(gbs, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
-                    launches=len(ms), mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min(ms) * 1e3, 2),
-                    algorithmic_bytes_per_launch=nbytes, timing="hip events on the launch stream, per launch")
+        step = dict(kernel="vqa_linf_step (stream4_kernel<StepOp>)", bound="hbm", achieved=round(gbs, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                    traffic=PMC_TRAFFIC_BYTES.get(self.step_numel), launches=n,
+                    mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
+                    algorithmic_bytes_per_launch=nbytes,
+                    timing="hip events on the launch stream, per launch; traffic = PMC bytes per launch (profiles/r01)")
+        loss = None
+        mean_ms, min_ms, n = self._stats(self.loss_events)
+        if n:
+            gbs = self.loss_bytes / mean_ms / 1e6
+            loss = dict(kernel="vqa_neg_cos_rows (+ vqa_sum_partials)", bound="hbm", achieved=round(gbs, 1),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
+                        mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
+                        algorithmic_bytes_per_launch=self.loss_bytes,
+                        note="12*D bytes per live row (read a, b; write grad); the event pair also covers the "
+                             "5 us partial-sum kernel and the gradient buffer allocation")
+        return step, loss
 
 
 def step_kernel_microbench(batch, image_size, reps=40):
@@ -194,7 +235,7 @@ def main():
 
     cfg = make_config(args)
     white = FrozenVlmo(cfg, seed=0).to(device)
-    black = FrozenVlmo(cfg, seed=1, vqa_head=True).to(device)
+    black = FrozenVlmo.finetuned_from(white, seed=1).to(device)   # VQA model = pre-trained trunk + drift + answer head
     adapters = VlmoAttackAdapters(white)
     attack = BatchedVQAttack(adapters, "vlmo", white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
@@ -223,7 +264,7 @@ def main():
         torch.cuda.synchronize()
         log("warmup step {} done".format(i))
     ledger.reset()
-    timer = StepKernelTimer()
+    timer = KernelTimer()
     timer.install()
     fence()
     t0 = time.perf_counter()
@@ -237,7 +278,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    roof = timer.summary()
+    roof, roof_loss = timer.summary()
     if rank == 0:
         log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 
@@ -256,6 +297,7 @@ def main():
                        "text_len": cfg.max_text_len, "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
             "roofline": roof,
+            "roofline_loss": roof_loss,
         }
         if not args.no_b256:
             try:

@@ -39,7 +39,9 @@ const char* vqa_error_string(int code);
 
 /* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
  *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
- *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 3) */
+ *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 3)
+ *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
+ *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup */
 int vqa_set_option(int option, int value);
 
 /* ---------------------------------------------------------------- L-infinity image update (hot)
@@ -143,6 +145,19 @@ int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, 
  * (the reference's float(loss.cpu()) host sync per step, projected_gradient_descent.py:145, is deferred). */
 int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
                      vqa_stream_t stream);
+
+/* Masked-LM cross entropy with ignore_index over K label sets, loss and gradient in one launch:
+ *   loss = sum_k mean_{r : labels[k][r] != ignore} ( logsumexp(logits[r,:]) - logits[r, labels[k][r]] )
+ * row_loss[r] receives row r's share (fold it with vqa_sum_partials(row_loss, rows, dst, acc, gscale));
+ * grad (nullable, (rows, V) contiguous) receives gscale * d loss / d logits.  labels is int64 [K][rows];
+ * inv_count is a K-float scratch the launch fills with 1/n_valid_k.  K <= vqa_ce_max_label_sets().
+ * Replaces F.cross_entropy(out[0].view(-1, 30522), y[0][...].view(-1), ignore_index=-100), its K-fold repetition for
+ * 3-d labels and the autograd backward: A-ch/attacks/fast_gradient_method.py:131-142, V-ch/...:115-126.
+ * Algorithmic bytes: 8*V per row (read the logits once from HBM, write the gradient once). */
+int vqa_ce_max_label_sets(void);
+int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
+                long ignore_index, float* inv_count, float* grad, float* row_loss, float gscale,
+                vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- text side
  * dst[b, k, :] = src[b, idx[k], :]  for src (B, L, D), idx int64[K] with 0 <= idx[k] < L.

@@ -327,3 +327,34 @@ def test_linf_step_full_size_properties(batch):
     inner = ((x - x0).abs() < eps - 2 * eps_iter) & (x.abs() < 1 - 2 * eps_iter)
     # (x + e) - x and x - (x - e) round independently: equal to one ulp of |x| <= 1
     assert torch.allclose((out - x)[inner], -(out_neg - x)[inner], rtol=0, atol=2e-7)
+
+
+# ----------------------------------------------------------------------------- fused MLM cross entropy
+@pytest.mark.parametrize("rows,k", [(12, 1), (7, 3), (2560, 1), (40, 5)], ids=str)
+def test_mlm_cross_entropy(rows, k):
+    import torch.nn.functional as F
+    ops = _ops()
+    r = np.random.RandomState(27)
+    v = 30522
+    logits = torch.from_numpy((r.standard_normal((rows, v)) * 3).astype(np.float32))
+    labels = torch.from_numpy(r.randint(0, v, (k, rows)))
+    labels[:, ::3] = -100
+    if k > 1:
+        labels[1, :] = -100 if rows < 10 else labels[1, :]      # a fully ignored label set on the small case
+        labels[1, 1] = 5
+    a = logits.clone().requires_grad_(True)
+    want = sum(F.cross_entropy(a, labels[i], ignore_index=-100) for i in range(k))
+    want.backward()
+    slot = torch.zeros(1, device=DEV)
+    g = ops.mlm_cross_entropy(logits.to(DEV), labels.to(DEV), slot, accumulate=False)
+    # tolerance: fp32 log-sum-exp over 30522 terms in a different order than ATen: 1e-5 relative on the loss,
+    # 1e-6 absolute + 1e-4 relative on gradient entries (each <= 1/n_valid)
+    assert torch.allclose(slot.cpu()[0], want.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(g.cpu(), a.grad, rtol=1e-4, atol=1e-7)
+    # loss only + scaling
+    ops.mlm_cross_entropy(logits.to(DEV), labels.to(DEV), slot, accumulate=True, gscale=-1.0, want_grad=False)
+    assert abs(float(slot.item())) <= 1e-4 * max(1.0, abs(float(want)))
+    # 3-d view of the logits (B, L, V) as the adapters return them
+    if rows % 4 == 0:
+        g3 = ops.mlm_cross_entropy(logits.to(DEV).reshape(4, rows // 4, v), labels.to(DEV), slot, accumulate=False)
+        assert g3.shape == (4, rows // 4, v) and torch.equal(g3.reshape(rows, v), g)

@@ -1,79 +1,90 @@
-"""Sweep the tuning knobs of the fused L-inf step kernel on one MI355X and print achieved algorithmic GB/s.
+"""Interleaved A/B sweep of the fused L-inf step kernel's tuning knobs on one MI355X.
 
-    python tools/microbench_step.py [--batch 64 256] [--reps 50]
+    python tools/microbench_step.py [--batch 64 256] [--rounds 5]
 
-Timing: torch.cuda.Event on torch's current stream (the stream the kernels are launched on), `reps` back-to-back
-launches per measurement, ping-ponging x/out so every launch reads and writes fresh lines.
+Two regimes per variant, medians over interleaved rounds in ONE process (cdna_hip_programming.md, rule 24):
+  warm: 20 back-to-back launches, ping-ponging x/out (what a micro-benchmark sees);
+  cold: every launch preceded by a 1 GiB fill that evicts L2 / Infinity Cache (what the PGD loop sees: a full
+        white-box forward + backward runs between two launches), timed per launch with HIP events.
 """
 import argparse
+import itertools
 import json
-
 import os
+import statistics
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqattack_amd import _hip, ops  # noqa: E402
 
-from vqattack_amd import _hip, ops
 
-
-def time_step(batch, reps, blocks_per_cu, nt):
-    lib = _hip.lib()
-    assert lib.vqa_set_option(0, blocks_per_cu) == 0 and lib.vqa_set_option(1, nt) == 0
+def setup(batch):
     shape = (batch, 3, 384, 384)
     gen = torch.Generator(device="cuda").manual_seed(0)
     x0 = torch.empty(shape, device="cuda").uniform_(-1, 1, generator=gen)
     x = torch.clamp(x0 + torch.empty(shape, device="cuda").uniform_(-0.125, 0.125, generator=gen), -1, 1)
     g = torch.randn(shape, device="cuda", generator=gen)
     g.view(-1)[::1000] = 0
-    bufs = [x, torch.empty_like(x)]
-    for i in range(5):
-        ops.linf_step(bufs[i & 1], g, x0, 0.01, 0.125, -1, 1, out=bufs[1 - (i & 1)])
-    torch.cuda.synchronize()
+    return x0, [x, torch.empty_like(x)], g
+
+
+def set_knobs(bpc, nt, unroll, chunked):
+    lib = _hip.lib()
+    for opt, val in ((0, bpc), (1, nt), (2, unroll), (3, chunked)):
+        assert lib.vqa_set_option(opt, val) == 0
+
+
+def warm(x0, bufs, g, reps=20):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.linf_step(bufs[0], g, x0, 0.01, 0.125, -1, 1, out=bufs[1])
     a.record()
     for i in range(reps):
         ops.linf_step(bufs[i & 1], g, x0, 0.01, 0.125, -1, 1, out=bufs[1 - (i & 1)])
     b.record()
     torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    nbytes = 16 * x.numel()
-    return ms, nbytes / ms / 1e6   # GB/s
+    return a.elapsed_time(b) / reps * 1e3
 
 
-def time_copy(batch, reps):
-    shape = (batch, 3, 384, 384)
-    src = torch.randn(shape, device="cuda")
-    dst = torch.empty_like(src)
-    for _ in range(5):
-        dst.copy_(src)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    return ms, 8 * src.numel() / ms / 1e6
+def cold(x0, bufs, g, flush, reps=4):
+    ts = []
+    for i in range(reps):
+        flush.fill_(float(i))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.linf_step(bufs[i & 1], g, x0, 0.01, 0.125, -1, 1, out=bufs[1 - (i & 1)])
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return statistics.median(ts)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, nargs="+", default=[64, 256])
-    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=5)
     args = ap.parse_args()
-    print(torch.cuda.get_device_name(0))
+    flush = torch.empty(256 * 1024 * 1024, device="cuda")   # 1 GiB
+    variants = [(bpc, nt, u, ch) for bpc, nt, u, ch in itertools.product((4, 8, 16), (1, 3), (2, 4, 8), (0, 1))]
     for batch in args.batch:
-        ms, gbs = time_copy(batch, args.reps)
-        print(json.dumps({"kernel": "torch copy_ (8 B/elem)", "batch": batch, "ms": round(ms, 4), "GB/s": round(gbs)}))
-        for bpc in (2, 4, 8, 16, 32):
-            for nt in (0, 1, 2, 3):
-                ms, gbs = time_step(batch, args.reps, bpc, nt)
-                print(json.dumps({"kernel": "vqa_linf_step", "batch": batch, "blocks_per_cu": bpc, "nt": nt,
-                                  "ms": round(ms, 4), "GB/s": round(gbs), "frac_of_8TBs": round(gbs / 8000, 3)}),
-                      flush=True)
+        x0, bufs, g = setup(batch)
+        nbytes = 16 * x0.numel()
+        res = {v: {"warm": [], "cold": []} for v in variants}
+        for _ in range(args.rounds):
+            for v in variants:
+                set_knobs(*v)
+                res[v]["warm"].append(warm(x0, bufs, g))
+                res[v]["cold"].append(cold(x0, bufs, g, flush))
+        rows = []
+        for v in variants:
+            w, c = statistics.median(res[v]["warm"]), statistics.median(res[v]["cold"])
+            rows.append(dict(batch=batch, blocks_per_cu=v[0], nt=v[1], unroll=v[2], chunked=v[3], warm_us=round(w, 2),
+                             warm_GBs=round(nbytes / w / 1e3), cold_us=round(c, 2), cold_GBs=round(nbytes / c / 1e3)))
+        for r in sorted(rows, key=lambda r: r["cold_us"]):
+            print(json.dumps(r), flush=True)
+        del x0, bufs, g
+    set_knobs(8, 3, 4, 0)
 
 
 if __name__ == "__main__":

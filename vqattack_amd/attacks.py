@@ -22,7 +22,6 @@ There is no CPU path: CPU tensors raise ``HipExtensionError``.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from ._hip import HipExtensionError, dev_f32
@@ -119,11 +118,12 @@ def _feature_pairs(out, y, flavor, vl):
     return [(out[1], y[1]), (out[2], y[2])]
 
 
-def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra_loss=None):
+def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=None):
     """Fused loss + gradient: one HIP pass per pair, then autograd through the model only.
 
-    loss = sign * (extra_scale * sum_pairs sum_rows -cos + extra_loss).  ``extra_loss`` is an optional autograd
-    scalar (the CE terms of the VLMO mixed loss) that is back-propagated in the same autograd sweep.
+    loss = sign * extra_scale * sum_pairs sum_rows -cos (+ whatever ``extra()`` adds).  ``extra`` is an optional
+    callable that accumulates further terms into the slot and returns ``(tensors, grads)`` to back-propagate in the
+    same autograd sweep (the CE terms of the VLMO mixed loss).
     """
     tensors, grads = [], []
     gscale = sign * extra_scale
@@ -141,33 +141,35 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra_los
         if needs_grad:
             tensors.append(o32)
             grads.append(ga)
-    if extra_loss is not None:
-        slot.word.add_(extra_loss.detach().to(torch.float32) * sign)
-        tensors.append(extra_loss)
-        grads.append(torch.full_like(extra_loss, float(sign)))
+    if extra is not None:
+        more_t, more_g = extra()
+        tensors += more_t
+        grads += more_g
     if not tensors:
         raise RuntimeError("model_fn's outputs do not depend on the attacked input (nothing requires grad)")
     torch.autograd.backward(tensors, grads, inputs=leaves)
 
 
-def _mlm_ce(logits, labels):
-    """CE over the MLM vocabulary; 2-d labels or the sum over K label sets of 3-d labels (B, K, L).
-    A: fast_gradient_method.py:131-142; V: :116-126.  (`reshape` where the reference's `view` would reject a
-    non-contiguous slice for batch > 1.)"""
-    flat = logits.reshape(-1, MLM_VOCAB)
+def _label_sets(labels):
+    """(K, rows) int64 label sets of the reference's MLM labels: 2-d (B, L) -> K = 1; 3-d (B, K, L) -> one set per
+    k, summed (A: fast_gradient_method.py:131-142; V: :116-126).  `reshape` where the reference's `view` would reject
+    the non-contiguous slice for batch > 1."""
     if labels.dim() == 2:
-        return F.cross_entropy(flat, labels.reshape(-1), ignore_index=-100)
+        return labels.reshape(1, -1)
     if labels.dim() == 3:
-        loss = F.cross_entropy(flat, labels[:, 0, :].reshape(-1), ignore_index=-100)
-        for k in range(1, labels.size(1)):
-            loss = loss + F.cross_entropy(flat, labels[:, k, :].reshape(-1), ignore_index=-100)
-        return loss
+        return labels.permute(1, 0, 2).reshape(labels.shape[1], -1)
     raise ValueError("MLM labels must be 2-d or 3-d")
 
 
-def _ce_backward(loss, slot, leaves, sign):
-    slot.word.copy_(loss.detach().to(torch.float32).reshape(1) * sign)
-    torch.autograd.backward([loss], [torch.full_like(loss, float(sign))], inputs=leaves)
+def _ce_backward(logits, label_sets, slot, leaves, sign, scale=1.0, accumulate=False):
+    """Fused cross entropy: loss into ``slot``; returns ``(tensors, grads)`` for the autograd sweep (one HIP launch)."""
+    if logits.shape[-1] != MLM_VOCAB:
+        logits = logits.reshape(-1, MLM_VOCAB)          # the reference's .view(-1, 30522)
+    l32 = logits if logits.dtype == torch.float32 else logits.to(torch.float32)
+    needs_grad = l32.requires_grad
+    g = ops.mlm_cross_entropy(l32.detach(), label_sets, slot.word, accumulate=accumulate, gscale=sign * scale,
+                              want_grad=needs_grad)
+    return ([l32], [g]) if needs_grad else ([], [])
 
 
 def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bkp=None, bkp_y=None, vl=False):
@@ -180,8 +182,8 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             if ls == 1:
                 _feature_loss_backward(pairs, slot, leaves, sign)
             elif ls == 0:
-                _ce_backward(F.cross_entropy(out[0].reshape(-1, MLM_VOCAB), y[0].reshape(-1), ignore_index=-100),
-                             slot, leaves, sign)
+                t, g = _ce_backward(out[0], y[0].reshape(1, -1), slot, leaves, sign)
+                torch.autograd.backward(t, g, inputs=leaves)
             else:
                 raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
             return
@@ -200,16 +202,18 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
         if ls == 1:
             _feature_loss_backward(_feature_pairs(out, y, flavor, vl=False), slot, leaves, sign)
         elif ls == 0:
-            _ce_backward(_mlm_ce(out[0], y[0]), slot, leaves, sign)
+            t, g = _ce_backward(out[0], _label_sets(y[0]), slot, leaves, sign)
+            if not t:
+                raise RuntimeError("model_fn's logits do not depend on the attacked input")
+            torch.autograd.backward(t, g, inputs=leaves)
         elif flavor == VLMO:
-            # mixed loss, V: fast_gradient_method.py:127-131 (no truncation in this branch)
-            flat = out[0].reshape(-1, MLM_VOCAB)
-            ce = 0.1 * F.cross_entropy(flat, y[0].reshape(-1), ignore_index=-100)
-            for syn in y[3]:
-                ce = ce + 0.1 * F.cross_entropy(flat, syn[0].reshape(-1), ignore_index=-100)
+            # mixed loss, V: fast_gradient_method.py:127-131 (no truncation in this branch): feature loss / (13*Ntok)
+            # + 0.1 * CE(labels) + 0.1 * sum over synonym label sets -- all CE terms in ONE fused launch
+            sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
             scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
             _feature_loss_backward([(out[1], y[1]), (out[2], y[2])], slot, leaves, sign, extra_scale=scale,
-                                   extra_loss=ce)
+                                   extra=lambda: _ce_backward(out[0], sets, slot, leaves, sign, scale=0.1,
+                                                              accumulate=True))
         else:
             raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
 

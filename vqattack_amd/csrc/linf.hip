@@ -14,6 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- tuning knobs (vqa_set_option), defaults chosen from the round-1 sweep recorded in DESIGN.md
 static int g_opt_blocks_per_cu = 8;   // option 0
 static int g_opt_nontemporal = 3;     // option 1: bit0 = nt loads of g, bit1 = nt stores of out
+static int g_opt_unroll = 4;          // option 2: 16-byte tiles in flight per lane and stream (2, 4 or 8)
+static int g_opt_chunked = 0;         // option 3: 0 = grid-stride tiles, 1 = one contiguous chunk per workgroup
 
 struct StepParams {
   float eps_iter, eps, cmin, cmax;
@@ -85,16 +87,20 @@ __global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // ma
                                                          const f32x4* __restrict__ s1,
                                                          const f32x4* __restrict__ s2,
                                                          f32x4* out, size_t n4,
-                                                         StepParams p, int* __restrict__ flag) {
+                                                         StepParams p, int* __restrict__ flag, size_t chunk) {
   const size_t tile = static_cast<size_t>(kBlock) * U;
-  const size_t stride = static_cast<size_t>(gridDim.x) * tile;
+  // chunk == 0: tiles are dealt round-robin over the grid; chunk > 0: workgroup b owns [b*chunk, (b+1)*chunk)
+  const size_t stride = chunk ? tile : static_cast<size_t>(gridDim.x) * tile;
+  const size_t first = chunk ? static_cast<size_t>(blockIdx.x) * chunk : static_cast<size_t>(blockIdx.x) * tile;
+  size_t last = chunk ? first + chunk : n4;
+  if (last > n4) last = n4;
   bool bad = false;
-  for (size_t base = static_cast<size_t>(blockIdx.x) * tile; base < n4; base += stride) {
+  for (size_t base = first; base < last; base += stride) {
     f32x4 v0[U], v1[U], v2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
-      if (i < n4) {
+      if (i < last) {
         v0[u] = s0[i];
         if (Op::kIn > 1) v1[u] = (NT & 1) ? __builtin_nontemporal_load(&s1[i]) : s1[i];
         if (Op::kIn > 2) v2[u] = s2[i];
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // ma
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
-      if (i < n4) {
+      if (i < last) {
         f32x4 r;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -134,6 +140,17 @@ __global__ __launch_bounds__(kBlock) void stream1_kernel(const float* s0,
 }
 
 template <class Op, int U>
+static void launch_vec(int nt, int grid, hipStream_t st, const f32x4* a0, const f32x4* a1, const f32x4* a2, f32x4* o,
+                       size_t n4, const StepParams& p, int* flag, size_t chunk) {
+  switch (nt & 3) {
+    case 0: stream4_kernel<Op, U, 0><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 2: stream4_kernel<Op, U, 2><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    default: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+  }
+}
+
+template <class Op, bool TUNABLE = false>
 static int launch_stream(const float* s0, const float* s1, const float* s2, float* out, size_t n,
                          const StepParams& p, int* flag, vqa_stream_t stream) {
   if (!s0 || !out || (Op::kIn > 1 && !s1) || (Op::kIn > 2 && !s2)) return VQA_ERR_NULL;
@@ -146,17 +163,20 @@ static int launch_stream(const float* s0, const float* s1, const float* s2, floa
   size_t done = 0;
   if (vec && n >= 4) {
     const size_t n4 = n / 4;
-    const int grid = blocks_for(n4, kBlock * U, 256 * g_opt_blocks_per_cu);
+    const int unroll = TUNABLE ? g_opt_unroll : 4;
+    const int grid = blocks_for(n4, kBlock * unroll, 256 * g_opt_blocks_per_cu);
+    size_t chunk = 0;
+    if (g_opt_chunked) {   // equal contiguous chunks, rounded up to whole tiles
+      const size_t tile = static_cast<size_t>(kBlock) * unroll;
+      chunk = ((n4 + grid - 1) / grid + tile - 1) / tile * tile;
+    }
     auto a0 = reinterpret_cast<const f32x4*>(s0);
     auto a1 = reinterpret_cast<const f32x4*>(s1);
     auto a2 = reinterpret_cast<const f32x4*>(s2);
     auto o = reinterpret_cast<f32x4*>(out);
-    switch (g_opt_nontemporal & 3) {
-      case 0: stream4_kernel<Op, U, 0><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
-      case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
-      case 2: stream4_kernel<Op, U, 2><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
-      default: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag); break;
-    }
+    if (TUNABLE && unroll == 2) launch_vec<Op, 2>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else launch_vec<Op, 4>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
     done = n4 * 4;
   }
   if (done < n) {
@@ -181,6 +201,13 @@ int vqa_set_option(int option, int value) {
     case 1:
       g_opt_nontemporal = value & 3;
       return VQA_OK;
+    case 2:
+      if (value != 2 && value != 4 && value != 8) return VQA_ERR_SHAPE;
+      g_opt_unroll = value;
+      return VQA_OK;
+    case 3:
+      g_opt_chunked = value ? 1 : 0;
+      return VQA_OK;
     default:
       return VQA_ERR_SHAPE;
   }
@@ -189,36 +216,36 @@ int vqa_set_option(int option, int value) {
 int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float eps, float cmin, float cmax,
                   unsigned mode, int* flag, vqa_stream_t stream) {
   StepParams p{0.0f, eps, cmin, cmax, mode};
-  if (eta) return launch_stream<InitOp, 4>(x, eta, nullptr, out, n, p, flag, stream);
-  return launch_stream<InitZeroOp, 4>(x, nullptr, nullptr, out, n, p, flag, stream);
+  if (eta) return launch_stream<InitOp>(x, eta, nullptr, out, n, p, flag, stream);
+  return launch_stream<InitZeroOp>(x, nullptr, nullptr, out, n, p, flag, stream);
 }
 
 int vqa_linf_fgm(const float* x, const float* g, float* out, size_t n, float eps_iter, float cmin, float cmax,
                  unsigned mode, int* flag, vqa_stream_t stream) {
   StepParams p{eps_iter, 0.0f, cmin, cmax, mode};
-  return launch_stream<FgmOp, 4>(x, g, nullptr, out, n, p, flag, stream);
+  return launch_stream<FgmOp>(x, g, nullptr, out, n, p, flag, stream);
 }
 
 int vqa_linf_step(const float* x, const float* g, const float* x0, float* out, size_t n, float eps_iter,
                   float eps, float cmin, float cmax, unsigned mode, int* flag, vqa_stream_t stream) {
   StepParams p{eps_iter, eps, cmin, cmax, mode};
-  return launch_stream<StepOp, 4>(x, g, x0, out, n, p, flag, stream);
+  return launch_stream<StepOp, true>(x, g, x0, out, n, p, flag, stream);
 }
 
 int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, float eps, float cmin,
                      float cmax, unsigned mode, vqa_stream_t stream) {
   StepParams p{0.0f, eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
-  return launch_stream<ProjectOp, 4>(adv, x0, nullptr, out, n, p, nullptr, stream);
+  return launch_stream<ProjectOp>(adv, x0, nullptr, out, n, p, nullptr, stream);
 }
 
 int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream) {
   StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
-  return launch_stream<ClipEtaOp, 4>(eta, nullptr, nullptr, out, n, p, nullptr, stream);
+  return launch_stream<ClipEtaOp>(eta, nullptr, nullptr, out, n, p, nullptr, stream);
 }
 
 int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream) {
   StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
-  return launch_stream<SignScaleOp, 4>(g, nullptr, nullptr, out, n, p, nullptr, stream);
+  return launch_stream<SignScaleOp>(g, nullptr, nullptr, out, n, p, nullptr, stream);
 }
 
 }  // extern "C"

@@ -299,6 +299,36 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
     return ga
 
 
+def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want_grad=True, ignore_index=-100):
+    """loss_out[0] (+)= gscale * sum_k CE_mean(logits, label_sets[k]); returns d(that)/d logits or None.
+
+    ``logits`` (..., V) fp32 with dense rows; ``label_sets`` int64 (K, rows) -- K label sets over the same rows
+    (K = 1 for the reference's 2-d labels, K = labels.shape[1] for its 3-d labels).
+    """
+    dev_f32(logits, "logits", contiguous=False)
+    v = logits.shape[-1]
+    flat = logits.reshape(-1, v)
+    if flat.stride(1) != 1:
+        flat = flat.contiguous()
+    rows = flat.shape[0]
+    if label_sets.dtype != torch.int64 or not label_sets.is_cuda:
+        raise TypeError("label_sets must be an int64 device tensor")
+    label_sets = label_sets.reshape(-1, rows).contiguous()
+    k = label_sets.shape[0]
+    if k > lib().vqa_ce_max_label_sets():
+        raise _hip.HipExtensionError("at most {} label sets per launch".format(lib().vqa_ce_max_label_sets()))
+    grad = torch.empty((rows, v), dtype=torch.float32, device=logits.device) if want_grad else None
+    inv_count = torch.empty(k, dtype=torch.float32, device=logits.device)
+    row_loss = torch.empty(max(rows, 1), dtype=torch.float32, device=logits.device)
+    with _on(logits):
+        st = stream_for(logits)
+        check(lib().vqa_ce_rows(ptr(flat), flat.stride(0), ctypes.c_void_p(label_sets.data_ptr()), k, rows, v,
+                                ignore_index, ptr(inv_count), ptr(grad), ptr(row_loss), gscale, st), "vqa_ce_rows")
+        check(lib().vqa_sum_partials(ptr(row_loss), rows, ptr(loss_out), 1 if accumulate else 0, gscale, st),
+              "vqa_sum_partials")
+    return grad.reshape(logits.shape) if want_grad else None
+
+
 # ----------------------------------------------------------------------------------------- text side
 def gather_rows(src, index):
     """src (B, L, D)[:, index] -> (B, K, D)."""

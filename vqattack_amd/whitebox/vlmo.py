@@ -165,6 +165,24 @@ class FrozenVlmo(nn.Module):
             normal_(self.mlm_bias)
             normal_(self.rel_pos_bias)
 
+    @classmethod
+    def finetuned_from(cls, white, seed=1, drift=0.25):
+        """Synthetic black box: the reference's VQA victim is the pre-trained white box after fine-tuning
+        (``reload_vqa`` / ``reload_pretrain`` swap two checkpoints of ONE architecture, vlmo_module.py:330-567), so its
+        trunk is a perturbed copy of the white box's -- every weight moves by ``drift`` of its own RMS -- plus a
+        freshly initialised answer head."""
+        black = cls(white.cfg, seed=seed, vqa_head=True)
+        g = torch.Generator().manual_seed(seed + 7919)
+        src = dict(white.named_parameters())
+        with torch.no_grad():
+            for name, p in black.named_parameters():
+                if name in src:
+                    w = src[name].detach().cpu()
+                    rms = float(w.pow(2).mean().sqrt())
+                    p.copy_(w + drift * rms * torch.empty(w.shape).normal_(generator=g))
+            black.rel_pos_bias.copy_(white.rel_pos_bias.detach().cpu())
+        return black
+
     # ---- embeddings -----------------------------------------------------------------------------------------
     def text_embeddings(self, ids):
         """BERT embeddings (word + type 0, then + position, LayerNorm); eval mode -> no dropout."""
