@@ -1,0 +1,32 @@
+"""hipGraph replay of PGD iterations must reproduce the eager loop bit for bit (same kernels, same order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_graphed_pgd_equals_eager(batch):
+    import vqattack_amd
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny
+    cfg = vlmo_tiny()
+    model = FrozenVlmo(cfg, seed=5).to(DEV)
+    ad = VlmoAttackAdapters(model)
+    ids = torch.tensor([[101, 2054, 3609, 2003, 102, 0, 0, 0]] * batch, device=DEV)
+    ad.set_text(ids, (ids != 0).long())
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.empty(batch, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g).to(DEV)
+    eta = torch.empty(x0.shape).uniform_(-0.125, 0.125, generator=g).to(DEV)
+    y = ad.gen_ori_feats(x0)
+    kw = dict(clip_min=-1, clip_max=1, ori_x=x0, time=0, ls=1, flavor="vlmo", init_eta=eta)
+    with torch.enable_grad():
+        adv_e, loss_e = vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, 7, np.inf, y=list(y), **kw)
+        adv_g, loss_g = vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, 7, np.inf, y=list(y),
+                                                                graph=True, **kw)
+    assert torch.equal(adv_e, adv_g)
+    assert loss_e == loss_g and len(loss_g) == 7
+    with pytest.raises(ValueError):
+        vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 2.0, 0.5, 2, 2, y=list(y), graph=True,
+                                                clip_min=-1, clip_max=1, ori_x=x0, time=1, ls=1, flavor="vlmo")

@@ -37,6 +37,7 @@ class AttackConfig:
     random_start: bool = True          # first block uses time=0 (uniform start), like the reference
     sanity_checks: bool = False        # the flag read is a host sync; parity tests switch it on
     sim_threshold: float = text_update.SIM_THRESHOLD   # adv_attack.py:303
+    use_graph: bool = False            # replay PGD iterations from a hipGraph (small, launch-bound batches)
 
 
 @dataclass
@@ -78,7 +79,7 @@ class BatchedVQAttack:
         a = self.adapters
         if not dual:
             return self.pgd(a.pgd_attack, adv, c.eps, c.eps_iter, steps, c.norm, y=self._y_feature(targets), ls=1,
-                            **common)
+                            graph=c.use_graph and steps > 2, **common)
         return self.pgd([a.pgd_attack, a.pgd_mlm_attack], adv, c.eps, c.eps_iter, steps // 2, c.norm,
                         y=self._y_dual(targets, mlm_labels), ls=0, **common)
 

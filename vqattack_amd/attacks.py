@@ -315,14 +315,51 @@ def _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks):
         assert np.all(ok)
 
 
+def _graphed_linf_loop(model_fn, cur, x0, y, flavor, targeted, eps_iter, eps, clip_min, clip_max, nb_iter, loss_buf):
+    """``nb_iter`` feature-loss L-inf iterations with iterations 1.. replayed from ONE captured hipGraph.
+
+    For the launch-bound regime (the reference's own batch 1: ~10^3 kernels of a few microseconds per iteration):
+    iteration 0 runs eagerly on a side stream (it is also the warm-up capture needs), iteration 1 is captured --
+    white-box forward, fused loss, autograd backward and the in-place fused step on the static image buffer --
+    and replayed.  Every C-ABI entry point is capture-safe (no allocation, no sync); the only eager op per
+    iteration is the 4-byte copy of the loss word into its slot of the loss buffer.
+    ``model_fn`` must be capturable: no host<->device copies or host RNG inside (ALBEF's per-forward token masking
+    is not; use ``mlm_probability=0`` or eager mode there).
+    """
+    word = torch.zeros(1, dtype=torch.float32, device=cur.device)
+
+    def iteration():
+        leaf = cur.detach().requires_grad_(True)
+        _loss_and_grad(model_fn, [leaf], leaf, y, 1, flavor, targeted, _LossSlot(word, 0))
+        ops.linf_step(cur, _grad_of(leaf), x0, eps_iter, eps, clip_min, clip_max, out=cur)   # in place: static address
+
+    main = torch.cuda.current_stream(cur.device)
+    side = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        iteration()
+        loss_buf[0:1].copy_(word)
+    main.wait_stream(side)
+    if nb_iter > 1:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            iteration()
+        for i in range(1, nb_iter):
+            graph.replay()
+            loss_buf[i:i + 1].copy_(word)
+    return cur
+
+
 def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_min=None, clip_max=None, y=None,
                                ori_x=None, time=None, targeted=False, rand_init=True, rand_minmax=None,
-                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None):
+                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None, graph=False):
     """PGD over a frozen white box; returns ``(adv_x, loss_list)``, bare ``x`` when eps or eps_iter is 0.
 
     ``ls == 1``: feature loss, ``model_fn`` a callable.  Otherwise the dual-loss loop: ``model_fn = [feature_fn,
     mlm_fn]``, one feature step then one MLM step per iteration with a single projection after both.
     ``init_eta`` (extension, keyword-only): the uniform draw to use when ``time == 0`` (for reproducible parity runs).
+    ``graph`` (extension, keyword-only): capture one iteration into a hipGraph and replay it (``ls == 1``, L-inf,
+    two-sided or no clipping; for small, launch-bound batches -- see ``_graphed_linf_loop``).
     Reference: A projected_gradient_descent.py:10-199, V :10-196.
     """
     _check_flavor(flavor)
@@ -342,6 +379,13 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     dual = ls != 1
     loss_buf = torch.zeros(max(nb_iter, 1) * (2 if dual else 1), dtype=torch.float32, device=xin.device)
     n_loss = 0
+    if graph and nb_iter > 0:
+        if dual or norm != np.inf:
+            raise ValueError("graph=True supports the feature-loss (ls == 1) L-inf loop only")
+        _two_sided(clip_min, clip_max)
+        adv = _graphed_linf_loop(model_fn, adv, x0, y, flavor, targeted, eps_iter, eps, clip_min, clip_max, nb_iter,
+                                 loss_buf)
+        n_loss, nb_iter = nb_iter, 0
     for _ in range(nb_iter):
         if not dual:
             leaf = adv.detach().requires_grad_(True)
