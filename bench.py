@@ -221,7 +221,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # any torchrun launch, also N = 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -239,7 +240,7 @@ def main():
     adapters = VlmoAttackAdapters(white)
     attack = BatchedVQAttack(adapters, "vlmo", white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
-    ledger = SuccessLedger(world, rank, device)
+    ledger = SuccessLedger(world, rank, device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     images = torch.empty(args.batch, 3, cfg.image_size, cfg.image_size, device=device).uniform_(-1, 1, generator=gen)
@@ -255,7 +256,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -274,7 +275,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.remove()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -307,7 +308,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

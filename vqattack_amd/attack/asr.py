@@ -18,8 +18,9 @@ def shard_indices(n_samples, rank, world):
 
 
 class SuccessLedger:
-    def __init__(self, world=1, rank=0, device="cpu"):
+    def __init__(self, world=1, rank=0, device="cpu", force_collective=False):
         self.world, self.rank, self.device = world, rank, torch.device(device)
+        self.force_collective = force_collective     # run the all-gather even for world == 1 (1-rank torchrun)
         self.reset()
 
     def reset(self):
@@ -43,7 +44,7 @@ class SuccessLedger:
         Ranks may hold different counts (5000 samples over 8 ranks): counts are gathered first, buffers padded."""
         bits = self.local_bits()
         ids = torch.cat(self._ids) if self._ids and len(self._ids) == len(self._bits) else None
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return bits, ids
         # one small gather carries (count, "I can supply ids") so every rank takes the same collective path
         has_ids = 1 if (ids is not None or bits.numel() == 0) else 0

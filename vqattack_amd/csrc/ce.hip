@@ -124,6 +124,116 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
   }
 }
 
+// Register-resident variant for V <= 32768 (the MLM vocabulary is 30522): the whole row is held as 32 float4 per
+// lane, so the logits cross HBM exactly once and nothing is re-read, not even from L2; max and sum-exp are plain
+// two-step block reductions (no serial online-rescale chain), exp() is evaluated once per element.
+// Rows of 30522 floats start 8 bytes off a 16-byte boundary every other row, so a row is split into a <= 3 element
+// head, a 16-byte aligned body of float4 and a <= 3 element tail (8-byte accesses run at 0.54-0.70x the 16-byte rate
+// on this chip, MI355X_MICROARCH.md).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
+static int g_ce_threads = 1024;       // vqa_set_option(4, 256 | 512 | 1024)
+
+template <bool GRAD, int MAXK, int THREADS>
+__global__ __launch_bounds__(THREADS) void ce_rows_reg_kernel(const float* __restrict__ logits, long row_stride,
+                                                             const int64_t* __restrict__ labels, int K, long rows,
+                                                             int V, long ignore_index,
+                                                             const float* __restrict__ inv_count,
+                                                             float* __restrict__ grad, float* __restrict__ row_loss,
+                                                             float gscale) {
+  constexpr int kQuads = kRegFloats / 4 / THREADS;
+  constexpr int kWavesT = THREADS / kWave;
+  __shared__ float lds[kWavesT];
+  const long r = blockIdx.x;
+  const float* x = logits + r * row_stride;
+  // logits base is 16-byte aligned (host check): alignment of the row start follows from its element offset
+  const int head = static_cast<int>((4 - ((r * row_stride) & 3)) & 3);
+  const int nquad = (V - head) / 4;
+  const int tail0 = head + 4 * nquad;              // first tail element
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + head);
+  f32x4 v[kQuads];
+#pragma unroll
+  for (int i = 0; i < kQuads; ++i) {
+    const int j = i * THREADS + threadIdx.x;
+    v[i] = (j < nquad) ? x4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  }
+  // the <= 6 leftover elements: lane t < head owns x[t]; lane 8 + t owns x[tail0 + t]
+  int edge = -1;
+  if (threadIdx.x < head) edge = threadIdx.x;
+  else if (threadIdx.x >= 8 && threadIdx.x < 8 + (V - tail0)) edge = tail0 + (threadIdx.x - 8);
+  float ve = (edge >= 0) ? x[edge] : -INFINITY;
+  float m = ve;
+#pragma unroll
+  for (int i = 0; i < kQuads; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+  m = wave_max(m);
+  if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = m;
+  __syncthreads();
+  m = lds[0];
+#pragma unroll
+  for (int w = 1; w < kWavesT; ++w) m = fmaxf(m, lds[w]);
+  __syncthreads();
+  ve = __expf(ve - m);                              // exp(-inf) = 0 for lanes without an edge element
+  float s = ve;
+#pragma unroll
+  for (int i = 0; i < kQuads; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = __expf(v[i][e] - m);
+      s += v[i][e];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = s;
+  __syncthreads();
+  s = lds[0];
+#pragma unroll
+  for (int w = 1; w < kWavesT; ++w) s += lds[w];
+  const float lse = m + logf(s);
+  long lab[MAXK];
+  float wk[MAXK];
+  float wsum = 0.0f, loss = 0.0f;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    lab[k] = -1;
+    wk[k] = 0.0f;
+    if (k < K) {
+      const long t = labels[static_cast<long>(k) * rows + r];
+      if (t != ignore_index && t >= 0 && t < V) {
+        lab[k] = t;
+        wk[k] = inv_count[k];
+        wsum += wk[k];
+        loss += wk[k] * (lse - x[t]);
+      }
+    }
+  }
+  if (threadIdx.x == 0) row_loss[r] = loss;
+  if (!GRAD) return;
+  float* g = grad + r * static_cast<long>(V);       // (rows, V) contiguous: same head/tail split as the logits row
+  const float c = wsum / s;
+  if (edge >= 0) {
+    float val = c * ve;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) val -= (lab[k] == edge) ? wk[k] : 0.0f;
+    g[edge] = gscale * val;
+  }
+  f32x4* g4 = reinterpret_cast<f32x4*>(g + head);
+#pragma unroll
+  for (int i = 0; i < kQuads; ++i) {
+    const int j = i * THREADS + threadIdx.x;
+    if (j < nquad) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float val = c * v[i][e];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) val -= (lab[k] == head + 4 * j + e) ? wk[k] : 0.0f;
+        o[e] = gscale * val;
+      }
+      __builtin_nontemporal_store(o, g4 + j);
+    }
+  }
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -131,6 +241,12 @@ using namespace vqa;
 extern "C" {
 
 int vqa_ce_max_label_sets(void) { return 8; }
+
+int vqa_ce_set_threads(int threads) {   // reached through vqa_set_option(4, threads)
+  if (threads != 256 && threads != 512 && threads != 1024) return VQA_ERR_SHAPE;
+  g_ce_threads = threads;
+  return VQA_OK;
+}
 
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
                 long ignore_index, float* inv_count, float* grad, float* row_loss, float gscale,
@@ -142,6 +258,18 @@ int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   ce_count_kernel<<<K, kBlock, 0, st>>>(labels, rows, ignore_index, inv_count);
   const int grid = static_cast<int>(rows);
+  // register path: row_stride == V keeps the gradient row's alignment phase equal to the logits row's
+  const bool reg_path = V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
+  if (reg_path) {
+#define VQA_CE_REG(G, T) \
+  ce_rows_reg_kernel<G, 8, T><<<grid, T, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count, \
+                                                  grad, row_loss, gscale)
+    if (g_ce_threads == 256) { if (grad) VQA_CE_REG(true, 256); else VQA_CE_REG(false, 256); }
+    else if (g_ce_threads == 512) { if (grad) VQA_CE_REG(true, 512); else VQA_CE_REG(false, 512); }
+    else { if (grad) VQA_CE_REG(true, 1024); else VQA_CE_REG(false, 1024); }
+#undef VQA_CE_REG
+    return launch_status();
+  }
   if (grad)
     ce_rows_kernel<true, 8><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count,
                                                      grad, row_loss, gscale);

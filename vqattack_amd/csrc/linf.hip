@@ -192,6 +192,8 @@ using namespace vqa;
 
 extern "C" {
 
+int vqa_ce_set_threads(int threads);   // ce.hip
+
 int vqa_set_option(int option, int value) {
   switch (option) {
     case 0:
@@ -208,6 +210,8 @@ int vqa_set_option(int option, int value) {
     case 3:
       g_opt_chunked = value ? 1 : 0;
       return VQA_OK;
+    case 4:
+      return vqa_ce_set_threads(value);
     default:
       return VQA_ERR_SHAPE;
   }
