@@ -177,6 +177,22 @@ int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, con
                      const float* beta, float ln_eps, const float* e_ori, const float* grad,
                      const int32_t* cand, float* out, int n_cand, int L, int K, int D, vqa_stream_t stream);
 
+/* ---------------------------------------------------------------- input pipeline
+ * Pillow-exact bicubic resize of an 8-bit interleaved image (H, W, C), C <= 4, then ToTensor + Normalize into planar
+ * fp32 -- what `transforms.Resize((res, res), interpolation=Image.BICUBIC)`, `ToTensor()`, `Normalize(0.5, 0.5)` do on
+ * the host in the reference (ALBEF_attack/dataset/__init__.py:17,35-39; vlmo/transforms/square_transform.py:11-18).
+ * kk int32 [out][ksize] fixed-point taps (22 fractional bits) and bounds int32 [out][2] = {first source index, tap
+ * count} are Pillow's precompute_coeffs + normalize_coeffs_8bpc tables (vqattack_amd/preprocess.py builds them).
+ *   pass 1: dst[y, xo, c] uint8 (H, W_out, C)         = horizontal resampling of src
+ *   pass 2: dst[c, yo, x] fp32  (C, H_out, W)          = (vertical resampling of src / 255 - mean) / std
+ *           (kk == NULL: no vertical resampling, requires H_in == H_out -- conversion only)
+ * dst of pass 2 is typically `batch + b*3*S*S`, the image's slot of the attack's (B, 3, S, S) tensor. */
+int vqa_resize_bicubic_h_u8(const uint8_t* src, int h, int w_in, int c, const int32_t* kk, const int32_t* bounds,
+                            int ksize, int w_out, uint8_t* dst, vqa_stream_t stream);
+int vqa_resize_bicubic_v_normalize(const uint8_t* src, int h_in, int w, int c, const int32_t* kk,
+                                   const int32_t* bounds, int ksize, int h_out, float mean, float stdv, float* dst,
+                                   vqa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,8 +49,10 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
     ledger = SuccessLedger(world, rank, device)
     buckets = bucket_by_schedule([int(att[i].sum()) for i in mine])
+    writer = None
     if save_dir:
-        os.makedirs(save_dir, exist_ok=True)
+        from ..preprocess import AdvImageWriter
+        writer = AdvImageWriter(save_dir, device)     # <qid>.pt, (1,3,H,W) fp32, like adv_attack.py:714
     adv_text = {}
     steps = 0
     done = 0
@@ -68,14 +70,15 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget)
             for q, row in zip(qids, res.adv_text_ids.cpu().tolist()):
                 adv_text[str(q)] = row
-            if save_dir:
-                for q, img in zip(qids, res.adv_images):
-                    torch.save(img[None].cpu().detach(), os.path.join(save_dir, "{}.pt".format(q)))
+            if writer is not None:
+                writer.write(res.adv_images, qids)
             done += len(qids)
             if rank == 0 and log_every and done % log_every < len(qids):
                 bits = ledger.local_bits()
                 print("attack_accuracy", float(bits.float().mean().item()), "({} local samples)".format(done),
                       flush=True)
+    if writer is not None:
+        writer.close()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     asr = ledger.all_gather_rate()
