@@ -177,6 +177,15 @@ int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, con
                      const float* beta, float ln_eps, const float* e_ori, const float* grad,
                      const int32_t* cand, float* out, int n_cand, int L, int K, int D, vqa_stream_t stream);
 
+/* Masked-token embedding substitution: BERT text embeddings for explicit triples {destination row, token position,
+ * vocabulary id}:  dst[row, :] = LayerNorm(word[id] + type[0] + pos[position]; gamma, beta, ln_eps), dst viewed as
+ * (rows, D).  With all B*L rows it embeds a question batch in one launch; with a short list it rewrites only the rows
+ * of the words the joint attack just substituted.  Replaces the re-tokenise + `text_embeddings(adv_text_ids)` calls
+ * between PGD blocks (ALBEF_attack/adv_attack.py:643-645,369-384; models/xbert.py:189-216).
+ * triples int32 [n][3]; D multiple of 4, <= 2048; the caller guarantees rows are distinct and in range. */
+int vqa_embed_tokens(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                     float ln_eps, const int32_t* triples, int n, float* dst, int D, vqa_stream_t stream);
+
 /* ---------------------------------------------------------------- input pipeline
  * Pillow-exact bicubic resize of an 8-bit interleaved image (H, W, C), C <= 4, then ToTensor + Normalize into planar
  * fp32 -- what `transforms.Resize((res, res), interpolation=Image.BICUBIC)`, `ToTensor()`, `Normalize(0.5, 0.5)` do on

@@ -358,3 +358,32 @@ def test_mlm_cross_entropy(rows, k):
     if rows % 4 == 0:
         g3 = ops.mlm_cross_entropy(logits.to(DEV).reshape(4, rows // 4, v), labels.to(DEV), slot, accumulate=False)
         assert g3.shape == (4, rows // 4, v) and torch.equal(g3.reshape(rows, v), g)
+
+
+# ----------------------------------------------------------------------------- masked-token embedding substitution
+@pytest.mark.parametrize("d", [768, 1024, 64])
+def test_embed_tokens(d):
+    ops = _ops()
+    from oracle import text_scoring as ts
+    r = np.random.RandomState(28)
+    vocab, length, nb = 700, 10, 5
+    f = lambda *s: torch.from_numpy(r.standard_normal(s).astype(np.float32))   # noqa: E731
+    word, pos, typ = f(vocab, d) * 0.05, f(64, d) * 0.05, f(2, d) * 0.05
+    gamma, beta = 1 + 0.1 * f(d), 0.1 * f(d)
+    tables = dict(word=word.to(DEV), pos=pos.to(DEV), type_emb=typ.to(DEV), gamma=gamma.to(DEV), beta=beta.to(DEV),
+                  ln_eps=1e-12)
+    ids = torch.from_numpy(r.randint(0, vocab, (nb, length)))
+    want = ts.bert_embeddings(ids, word, pos, typ, gamma, beta, 1e-12)
+    got = ops.embed_tokens(tables, ids.to(DEV))
+    # tolerance: fp32 LayerNorm with a different reduction order than ATen: 2e-6 absolute on O(1) values
+    assert torch.allclose(got.cpu(), want, rtol=0, atol=2e-6)
+    # substitute two words and rewrite only their rows
+    new_ids = ids.clone()
+    new_ids[1, 3], new_ids[4, 7] = 5, 6
+    before = got.clone()
+    ops.embed_tokens(tables, new_ids.to(DEV), out=got, rows=[(1, 3), (4, 7)])
+    want2 = ts.bert_embeddings(new_ids, word, pos, typ, gamma, beta, 1e-12)
+    assert torch.allclose(got.cpu(), want2, rtol=0, atol=2e-6)
+    untouched = torch.ones(nb, length, dtype=torch.bool)
+    untouched[1, 3] = untouched[4, 7] = False
+    assert torch.equal(got.cpu()[untouched], before.cpu()[untouched])

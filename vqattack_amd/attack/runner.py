@@ -21,7 +21,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from .. import dropin
+from .. import dropin, ops
 from . import text_update
 from .schedule import IMAGE_STEP_BUDGET, iter_schedule
 
@@ -115,7 +115,10 @@ class BatchedVQAttack:
                 if fn is not None:
                     proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
                                                                banned=self.banned_ids)
-            e_ori = a.text_embeddings(text_ids)
+            # text embeddings of the question batch: one launch; after every substitution round only the rows of the
+            # replaced words are rewritten (masked-token embedding substitution, ops.embed_tokens)
+            e_ori = ops.embed_tokens(self.tables, text_ids)
+            adv_emb = e_ori.clone()
             ori_host = text_ids.cpu().numpy()
             positions = list(range(text_ids.shape[1]))
             for bi, steps in enumerate(blocks):
@@ -128,7 +131,7 @@ class BatchedVQAttack:
                 if bi == len(blocks) - 1:
                     break
                 with torch.enable_grad():
-                    adv, text_grad = self.pgd_vl(a.pgd_attack_vl, [adv, a.text_embeddings(adv_ids)], c.eps, c.eps_iter,
+                    adv, text_grad = self.pgd_vl(a.pgd_attack_vl, [adv, adv_emb], c.eps, c.eps_iter,
                                                  1, c.norm, clip_min=c.clip_min, clip_max=c.clip_max,
                                                  y=self._y_feature(targets), time=1, ori_x=images, ls=1,
                                                  attack_mask=positions, sanity_checks=c.sanity_checks)
@@ -139,5 +142,8 @@ class BatchedVQAttack:
                                                               self.similarity_fn, c.sim_threshold)
                     adv_ids = torch.as_tensor(new_ids, device=text_ids.device, dtype=text_ids.dtype)
                     res.substitutions.append(subs)
+                    changed = [(s, p) for s, per in enumerate(subs) for (p, _, _) in per]
+                    if changed:
+                        ops.embed_tokens(self.tables, adv_ids, out=adv_emb, rows=changed)
         res.adv_images, res.adv_text_ids = adv, adv_ids
         return res

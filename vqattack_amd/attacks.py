@@ -24,8 +24,8 @@ import numpy as np
 import torch
 
 from . import ops
-from ._hip import HipExtensionError, dev_f32
-from .features import LayerFeatures, layer_pairs
+from ._hip import HipExtensionError
+from .features import layer_pairs
 
 ALBEF = "albef"
 VLMO = "vlmo"

@@ -109,6 +109,70 @@ __global__ __launch_bounds__(kBlock) void cand_dir_sim_kernel(
   }
 }
 
+// BERT text embeddings for explicit (row, position, token) triples: dst[row[i]] = LN(word[tok[i]] + type[0] + pos[position[i]]).
+// With rows = 0..B*L-1 this embeds a whole question batch in one launch (instead of gather + add + add + LayerNorm);
+// with a short list it overwrites only the rows of substituted words (the joint attack's masked-token substitution).
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void embed_tokens_kernel(const float* __restrict__ word,
+                                                              const float* __restrict__ pos,
+                                                              const float* __restrict__ type,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float ln_eps,
+                                                              const int32_t* __restrict__ triples, int n,
+                                                              float* __restrict__ dst, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int i = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave; i < n; i += gridDim.x * kWavesPerBlock) {
+    const long row = triples[3 * i + 0];
+    const float* pw = word + static_cast<long>(triples[3 * i + 2]) * D;
+    const float* pp = pos + static_cast<long>(triples[3 * i + 1]) * D;
+    f32x4 e[NCH];
+    float sum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+        f32x4 w = *reinterpret_cast<const f32x4*>(pw + d);
+        f32x4 q = *reinterpret_cast<const f32x4*>(pp + d);
+        f32x4 t = *reinterpret_cast<const f32x4*>(type + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[ch][j] = (w[j] + t[j]) + q[j];
+          sum += e[ch][j];
+        }
+      } else {
+        e[ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+    const float mean = wave_sum(sum) / static_cast<float>(D);
+    float var = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c0 = e[ch][j] - mean;
+          var += c0 * c0;
+        }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / static_cast<float>(D) + ln_eps);
+    float* out = dst + row * D;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int d = (ch * kWave + lane) * 4;
+      if (d < D) {
+        f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + d);
+        f32x4 be = *reinterpret_cast<const f32x4*>(beta + d);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (e[ch][j] - mean) * rstd * ga[j] + be[j];
+        *reinterpret_cast<f32x4*>(out + d) = r;
+      }
+    }
+  }
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -152,6 +216,32 @@ int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, con
     default: VQA_CAND(8); break;
   }
 #undef VQA_CAND
+  return launch_status();
+}
+
+int vqa_embed_tokens(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                     float ln_eps, const int32_t* triples, int n, float* dst, int D, vqa_stream_t stream) {
+  if (!word || !pos || !type || !gamma || !beta || !triples || !dst) return VQA_ERR_NULL;
+  if (n < 0 || D <= 0 || D > 256 * kMaxCh || (D & 3)) return VQA_ERR_SHAPE;
+  if (!aligned16(word) || !aligned16(pos) || !aligned16(type) || !aligned16(gamma) || !aligned16(beta) ||
+      !aligned16(dst))
+    return VQA_ERR_ALIGN;
+  if (n == 0) return VQA_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = blocks_for(static_cast<size_t>(n), kWavesPerBlock);
+#define VQA_EMB(N) \
+  embed_tokens_kernel<N><<<grid, kBlock, 0, st>>>(word, pos, type, gamma, beta, ln_eps, triples, n, dst, D)
+  switch ((D + 255) / 256) {
+    case 1: VQA_EMB(1); break;
+    case 2: VQA_EMB(2); break;
+    case 3: VQA_EMB(3); break;
+    case 4: VQA_EMB(4); break;
+    case 5: VQA_EMB(5); break;
+    case 6: VQA_EMB(6); break;
+    case 7: VQA_EMB(7); break;
+    default: VQA_EMB(8); break;
+  }
+#undef VQA_EMB
   return launch_status();
 }
 

@@ -5,7 +5,6 @@ Every function launches on the current HIP stream of its tensors' device and ret
 """
 import contextlib
 import ctypes
-import math
 
 import torch
 
@@ -369,4 +368,38 @@ def cand_dir_sim(word, pos, type_emb, gamma, beta, ln_eps, e_ori, grad, cand):
         check(lib().vqa_cand_dir_sim(ptr(word), ptr(pos), ptr(type_emb), ptr(gamma), ptr(beta), ln_eps, ptr(e_ori),
                                      ptr(grad), ctypes.c_void_p(cand.data_ptr()), ptr(out), n, l, k, d,
                                      stream_for(word)), "vqa_cand_dir_sim")
+    return out
+
+
+def embed_tokens(tables, text_ids, out=None, rows=None):
+    """BERT embeddings ``LN(word[id] + type[0] + pos[p])`` on the device in one launch.
+
+    ``text_ids`` (B, L) int64.  ``rows=None`` embeds every token into a fresh (or given) ``(B, L, D)`` tensor;
+    ``rows`` = int tensor/list of ``(sample, position)`` pairs rewrites only those rows of ``out`` in place (the words
+    the joint attack just substituted) using the ids currently in ``text_ids``.
+    """
+    word = tables["word"]
+    dev_f32(word, "word")
+    b, l = text_ids.shape
+    d = word.shape[1]
+    if out is None:
+        if rows is not None:
+            raise ValueError("rows=... updates an existing embedding tensor: pass out=")
+        out = torch.empty(b, l, d, dtype=torch.float32, device=word.device)
+    else:
+        dev_f32(out, "out")
+        if tuple(out.shape) != (b, l, d):
+            raise ValueError("out must be ({}, {}, {})".format(b, l, d))
+    ids = text_ids.to(word.device)
+    if rows is None:
+        s_idx = torch.arange(b, device=word.device).repeat_interleave(l)
+        p_idx = torch.arange(l, device=word.device).repeat(b)
+    else:
+        rows = torch.as_tensor(rows, device=word.device, dtype=torch.int64).reshape(-1, 2)
+        s_idx, p_idx = rows[:, 0], rows[:, 1]
+    triples = torch.stack([s_idx * l + p_idx, p_idx, ids[s_idx, p_idx]], dim=1).to(torch.int32).contiguous()
+    with _on(word):
+        check(lib().vqa_embed_tokens(ptr(word), ptr(tables["pos"]), ptr(tables["type_emb"]), ptr(tables["gamma"]),
+                                     ptr(tables["beta"]), tables["ln_eps"], ctypes.c_void_p(triples.data_ptr()),
+                                     triples.shape[0], ptr(out), d, stream_for(word)), "vqa_embed_tokens")
     return out
