@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--pgd-steps", type=int, default=40)
     ap.add_argument("--image-size", type=int, default=384)
-    ap.add_argument("--model", default="vlmo_base", choices=["vlmo_base", "vlmo_large", "vlmo_tiny"])
+    ap.add_argument("--model", default="vlmo_base",
+                    choices=["vlmo_base", "vlmo_large", "vlmo_tiny", "albef_base", "albef_tiny"])
+    ap.add_argument("--joint", type=int, default=0, metavar="WORDS",
+                    help="joint image+text attack with this many substitutable words per question (configs[4]); "
+                         "0 = image-only PGD (configs[1], the default metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
     ap.add_argument("--no-b256", action="store_true")
@@ -58,10 +62,27 @@ def synthetic_questions(batch, length, n_body, seed, device):
 
 
 def make_config(args):
-    from vqattack_amd.whitebox import vlmo
+    from vqattack_amd.whitebox import albef, vlmo
     if args.model == "vlmo_tiny":
         return vlmo.vlmo_tiny()
+    if args.model == "albef_tiny":
+        return albef.albef_tiny()
+    if args.model == "albef_base":
+        return albef.albef_base(image_size=args.image_size)
     return getattr(vlmo, args.model)(image_size=args.image_size)
+
+
+def build_models(args, cfg, device):
+    """(flavor, white box, black box, adapters, text length)."""
+    if args.model.startswith("albef"):
+        from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef
+        white = FrozenAlbef(cfg, seed=0).to(device)
+        black = FrozenAlbef(cfg, seed=1, vqa_head=True).to(device)
+        return "albef", white, black, AlbefAttackAdapters(white), (8 if args.model == "albef_tiny" else 40)
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters
+    white = FrozenVlmo(cfg, seed=0).to(device)
+    black = FrozenVlmo.finetuned_from(white, seed=1).to(device)   # VQA model = pre-trained trunk + drift + answer head
+    return "vlmo", white, black, VlmoAttackAdapters(white), cfg.max_text_len
 
 
 # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
@@ -232,24 +253,24 @@ def main():
 
     from vqattack_amd.attack.asr import SuccessLedger
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
-    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters
 
     cfg = make_config(args)
-    white = FrozenVlmo(cfg, seed=0).to(device)
-    black = FrozenVlmo.finetuned_from(white, seed=1).to(device)   # VQA model = pre-trained trunk + drift + answer head
-    adapters = VlmoAttackAdapters(white)
-    attack = BatchedVQAttack(adapters, "vlmo", white.embedding_tables(),
+    flavor, white, black, adapters, text_len = build_models(args, cfg, device)
+    attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
     ledger = SuccessLedger(world, rank, device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     images = torch.empty(args.batch, 3, cfg.image_size, cfg.image_size, device=device).uniform_(-1, 1, generator=gen)
-    ids, masks = synthetic_questions(args.batch, cfg.max_text_len, 8, seed=100 + rank, device=device)
-    no_words = torch.zeros_like(ids, dtype=torch.bool)           # configs[1]: image-only 40-step PGD
+    n_body = max(args.joint, 8)
+    ids, masks = synthetic_questions(args.batch, text_len, n_body, seed=100 + rank, device=device)
+    words = torch.zeros_like(ids, dtype=torch.bool)              # configs[1]: image-only 40-step PGD
+    if args.joint:
+        words[:, 1:1 + min(args.joint, text_len - 2)] = True     # configs[4]: joint image + text attack
     clean_answers = black.vqa_answer(images, ids, masks)
 
     def one_step():
-        res = attack.attack_batch(images, ids, masks, no_words)
+        res = attack.attack_batch(images, ids, masks, words)
         adv_answers = black.vqa_answer(res.adv_images, res.adv_text_ids, masks)
         ledger.record(adv_answers != clean_answers)
         return res
@@ -289,13 +310,15 @@ def main():
             "metric": "adversarial_vqa_examples_per_sec", "value": round(total / dt, 4), "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "{} VQAttack image PGD (BASELINE configs[1]): batch {} per GPU, {} PGD steps, "
+            "config": {"workload": "{} VQAttack {} (BASELINE configs[{}]): batch {} per GPU, {} PGD steps, "
                                    "{}x{} images, {}-token questions, eps 0.125 step 0.01 L-inf clip [-1,1], random start, "
-                                   "black-box scoring + ASR gather".format(args.model, args.batch, args.pgd_steps,
-                                                                           cfg.image_size, cfg.image_size,
-                                                                           cfg.max_text_len),
+                                   "black-box scoring + ASR gather".format(
+                                       args.model, "joint image+text attack ({} words)".format(args.joint)
+                                       if args.joint else "image PGD", 4 if args.joint else 1, args.batch,
+                                       args.pgd_steps, cfg.image_size, cfg.image_size, text_len),
                        "batch_per_gpu": args.batch, "pgd_steps": args.pgd_steps, "image_size": cfg.image_size,
-                       "text_len": cfg.max_text_len, "sharding": "independent batches per rank, all-gather of success bits"},
+                       "text_len": text_len, "substitutable_words": args.joint,
+                       "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
             "roofline": roof,
             "roofline_loss": roof_loss,
@@ -305,7 +328,7 @@ def main():
                 line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
             except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
                 line["roofline_b256"] = {"error": str(exc)[:200]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and flavor == "vlmo":
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
     if use_dist:
