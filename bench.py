@@ -96,7 +96,7 @@ class KernelTimer:
 
     def __init__(self):
         self.step_events, self.step_numel = [], 0
-        self.loss_events, self.loss_bytes = [], 0
+        self.loss_events, self.loss_bytes = [], []
         self._live = {}
 
     def install(self):
@@ -126,7 +126,7 @@ class KernelTimer:
                 if key not in timer._live:
                     timer._live[key] = int((w != 0).sum().item())
                 rows = timer._live[key] * (rows // w.numel())
-            timer.loss_bytes = (12 if out is not None else 8) * rows * a_.shape[-1]
+            timer.loss_bytes.append((12 if out is not None else 8) * rows * a_.shape[-1])
             return out
         ops.linf_step, ops.neg_cos_rows = timed_step, timed_loss
 
@@ -155,11 +155,12 @@ class KernelTimer:
         loss = None
         mean_ms, min_ms, n = self._stats(self.loss_events)
         if n:
-            gbs = self.loss_bytes / mean_ms / 1e6
+            total_bytes = sum(self.loss_bytes)           # launches differ in size (text / image rows): bytes over time
+            gbs = total_bytes / (mean_ms * n) / 1e6
             loss = dict(kernel="vqa_neg_cos_rows (+ vqa_sum_partials)", bound="hbm", achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
-                        algorithmic_bytes_per_launch=self.loss_bytes,
+                        algorithmic_bytes_per_launch=round(total_bytes / n),
                         note="12*D bytes per live row (read a, b; write grad); the event pair also covers the "
                              "5 us partial-sum kernel and the gradient buffer allocation")
         return step, loss

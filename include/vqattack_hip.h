@@ -39,7 +39,7 @@ const char* vqa_error_string(int code);
 
 /* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
  *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
- *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 3)
+ *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1)
  *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
  *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup
  *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 1024) */

@@ -73,6 +73,11 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # development overrides of the tuning knobs: VQA_OPTIONS="1=3,0=8" -> vqa_set_option(1, 3); vqa_set_option(0, 8)
+    for item in filter(None, os.environ.get("VQA_OPTIONS", "").split(",")):
+        opt, val = item.split("=")
+        if lib.vqa_set_option(int(opt), int(val)) != 0:
+            raise HipExtensionError("bad VQA_OPTIONS entry '{}'".format(item))
     return lib
 
 

@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- tuning knobs (vqa_set_option), defaults chosen from the round-1 sweep recorded in DESIGN.md
 static int g_opt_blocks_per_cu = 8;   // option 0
-static int g_opt_nontemporal = 3;     // option 1: bit0 = nt loads of g, bit1 = nt stores of out
+static int g_opt_nontemporal = 1;     // option 1: bit0 = nt loads of g, bit1 = nt stores of out (in-situ A/B)
 static int g_opt_unroll = 4;          // option 2: 16-byte tiles in flight per lane and stream (2, 4 or 8)
 static int g_opt_chunked = 0;         // option 3: 0 = grid-stride tiles, 1 = one contiguous chunk per workgroup
 

@@ -227,10 +227,12 @@ _partials = {}
 
 
 def _partial_buf(device):
-    buf = _partials.get(device)
+    """Per-(device, stream) scratch for the loss partials: launches on one stream are ordered, so reuse is safe."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _partials.get(key)
     if buf is None:
         buf = torch.empty(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
-        _partials[device] = buf
+        _partials[key] = buf
     return buf
 
 
