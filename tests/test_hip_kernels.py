@@ -387,3 +387,19 @@ def test_embed_tokens(d):
     untouched = torch.ones(nb, length, dtype=torch.bool)
     untouched[1, 3] = untouched[4, 7] = False
     assert torch.equal(got.cpu()[untouched], before.cpu()[untouched])
+
+
+# ----------------------------------------------------------------------------- empty inputs
+def test_empty_inputs_are_no_ops():
+    ops = _ops()
+    from vqattack_amd import utils
+    e = torch.empty(0, 3, 8, 8, device=DEV)
+    assert ops.linf_step(e, e, e, 0.01, 0.125, -1, 1).shape == e.shape
+    assert ops.linf_init(e, None, 0.125, -1, 1).shape == e.shape
+    assert utils.clip_eta(e, np.inf, 0.1).shape == e.shape
+    assert utils.optimize_linear(e, 0.1, np.inf).shape == e.shape
+    assert ops.sumsq_per_sample(e).shape == (0,)
+    slot = torch.ones(1, device=DEV)
+    ga = ops.neg_cos_rows(torch.empty(0, 5, 16, device=DEV), torch.empty(0, 5, 16, device=DEV), slot, accumulate=False)
+    assert ga.shape == (0, 5, 16) and float(slot) == 0.0
+    assert ops.gather_rows(torch.empty(0, 4, 16, device=DEV), [1, 2]).shape == (0, 2, 16)
