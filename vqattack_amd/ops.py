@@ -56,6 +56,8 @@ def linf_init(x, eta, eps, clip_min, clip_max, flag=None, out=None):
     mode, lo, hi = _clip_args(clip_min, clip_max)
     if flag is not None and mode:
         mode |= VQA_CHECK_RANGE
+    if x.numel() == 0:
+        return out
     with _on(x):
         check(lib().vqa_linf_init(ptr(x), ptr(eta), ptr(out), x.numel(), eps, lo, hi, mode, ptr(flag),
                                   stream_for(x)), "vqa_linf_init")
@@ -71,6 +73,8 @@ def linf_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     mode, lo, hi = _clip_args(clip_min, clip_max)
     if flag is not None and mode:
         mode |= VQA_CHECK_RANGE
+    if x.numel() == 0:
+        return out
     with _on(x):
         check(lib().vqa_linf_fgm(ptr(x), ptr(g), ptr(out), x.numel(), eps_iter, lo, hi, mode, ptr(flag),
                                  stream_for(x)), "vqa_linf_fgm")
@@ -88,6 +92,8 @@ def linf_step(x, g, x0, eps_iter, eps, clip_min, clip_max, flag=None, out=None):
     mode, lo, hi = _clip_args(clip_min, clip_max)
     if flag is not None and mode:
         mode |= VQA_CHECK_RANGE
+    if x.numel() == 0:
+        return out
     with _on(x):
         check(lib().vqa_linf_step(ptr(x), ptr(g), ptr(x0), ptr(out), x.numel(), eps_iter, eps, lo, hi, mode,
                                   ptr(flag), stream_for(x)), "vqa_linf_step")
@@ -101,6 +107,8 @@ def linf_project(adv, x0, eps, clip_min, clip_max, out=None):
     same_device(adv, x0, out)
     out = _out_like(adv, out)
     mode, lo, hi = _clip_args(clip_min, clip_max)
+    if adv.numel() == 0:
+        return out
     with _on(adv):
         check(lib().vqa_linf_project(ptr(adv), ptr(x0), ptr(out), adv.numel(), eps, lo, hi, mode,
                                      stream_for(adv)), "vqa_linf_project")
@@ -110,6 +118,8 @@ def linf_project(adv, x0, eps, clip_min, clip_max, out=None):
 def clip_eta_linf(eta, eps):
     dev_f32(eta, "eta")
     out = torch.empty_like(eta)
+    if eta.numel() == 0:
+        return out
     with _on(eta):
         check(lib().vqa_clip_eta_linf(ptr(eta), ptr(out), eta.numel(), eps, stream_for(eta)), "vqa_clip_eta_linf")
     return out
@@ -118,6 +128,8 @@ def clip_eta_linf(eta, eps):
 def optimize_linear_linf(grad, eps):
     dev_f32(grad, "grad")
     out = torch.empty_like(grad)
+    if grad.numel() == 0:
+        return out
     with _on(grad):
         check(lib().vqa_optimize_linear_linf(ptr(grad), ptr(out), grad.numel(), eps, stream_for(grad)),
               "vqa_optimize_linear_linf")
@@ -146,6 +158,8 @@ def sumsq_per_sample(t, sub=None):
             raise ValueError("shape mismatch")
     batch, n_per = _per_sample(t)
     out = torch.empty(batch, dtype=torch.float32, device=t.device)
+    if t.numel() == 0:
+        return out.zero_()
     ws = _workspace(t)
     with _on(t):
         check(lib().vqa_sumsq_per_sample(ptr(t), ptr(sub), ptr(out), batch, n_per, ptr(ws), stream_for(t)),
@@ -158,6 +172,8 @@ def absmax_ties_per_sample(g):
     batch, n_per = _per_sample(g)
     amax = torch.empty(batch, dtype=torch.float32, device=g.device)
     ties = torch.empty(batch, dtype=torch.float32, device=g.device)
+    if g.numel() == 0:
+        return amax.zero_(), ties.zero_()
     ws = _workspace(g)
     with _on(g):
         check(lib().vqa_absmax_ties_per_sample(ptr(g), ptr(amax), ptr(ties), batch, n_per, ptr(ws), stream_for(g)),
@@ -175,6 +191,8 @@ def l2_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     mode, lo, hi = _clip_args(clip_min, clip_max)
     if flag is not None and mode:
         mode |= VQA_CHECK_RANGE
+    if x.numel() == 0:
+        return out
     with _on(x):
         check(lib().vqa_l2_fgm(ptr(x), ptr(g), ptr(ss), ptr(out), batch, n_per, eps_iter, lo, hi, mode, ptr(flag),
                                stream_for(x)), "vqa_l2_fgm")
@@ -189,6 +207,8 @@ def l2_project(adv, x0, eps, clip_min, clip_max, out=None):
     out = _out_like(adv, out)
     batch, n_per = _per_sample(adv)
     mode, lo, hi = _clip_args(clip_min, clip_max)
+    if adv.numel() == 0:
+        return out
     with _on(adv):
         check(lib().vqa_l2_project(ptr(adv), ptr(x0), ptr(ss), ptr(out), batch, n_per, eps, lo, hi, mode,
                                    stream_for(adv)), "vqa_l2_project")
@@ -205,6 +225,8 @@ def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     mode, lo, hi = _clip_args(clip_min, clip_max)
     if flag is not None and mode:
         mode |= VQA_CHECK_RANGE
+    if x.numel() == 0:
+        return out
     with _on(x):
         check(lib().vqa_l1_fgm(ptr(x), ptr(g), ptr(amax), ptr(ties), ptr(out), batch, n_per, eps_iter, lo, hi, mode,
                                ptr(flag), stream_for(x)), "vqa_l1_fgm")
@@ -215,6 +237,8 @@ def scale_per_sample(t, stat, stat2, eps, kind, out=None):
     dev_f32(t, "t"), dev_f32(stat, "stat")
     out = _out_like(t, out)
     batch, n_per = _per_sample(t)
+    if t.numel() == 0:
+        return out
     with _on(t):
         check(lib().vqa_scale_per_sample(ptr(t), ptr(stat), ptr(stat2), ptr(out), batch, n_per, eps, kind,
                                          stream_for(t)), "vqa_scale_per_sample")
@@ -290,6 +314,10 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
         if row_weight.numel() != weight_period * r1:
             raise ValueError("row_weight has {} entries, expected weight_period*rows1 = {}".format(
                 row_weight.numel(), weight_period * r1))
+    if a.numel() == 0:                 # no rows: zero loss contribution, empty gradient
+        if not accumulate:
+            loss_out.zero_()
+        return ga
     part = _partial_buf(a.device)
     with _on(a):
         st = stream_for(a)
