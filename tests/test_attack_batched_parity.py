@@ -92,3 +92,37 @@ def test_albef_masking_is_reproducible_and_respects_specials():
     assert torch.equal(a[:, 0], ids[:, 0])                       # [CLS] never masked
     assert torch.equal(a[ids == 0], ids[ids == 0])               # padding never masked
     assert torch.equal(ids, IDS)                                 # input untouched
+
+
+@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
+def test_batched_dual_loss_attack_matches_per_sample_oracle(flavor):
+    """Dual-loss blocks (feature step + MLM step per iteration, `old_alg == 0` in the reference).  The MLM cross entropy
+    is a mean over the valid tokens of the whole batch here and of one sample in the reference: a positive per-sample
+    scale that `sign()` cannot see, so the perturbations must still agree; loss VALUES of the MLM steps are not compared."""
+    import numpy as np
+    from oracle import cleverhans_cpu as o
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    cpu_model, gpu_model, adapters_cls, ref_cls, cfg = _build(flavor)
+    g = torch.Generator().manual_seed(21)
+    images = torch.empty(3, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(images).uniform_(-0.125, 0.125, generator=g)
+    masks = (IDS != 0).long()
+    labels = torch.full_like(IDS, -100)
+    labels[0, 2], labels[1, 3], labels[2, 1] = 2003, 2024, 2054            # one masked word per question
+    attack = BatchedVQAttack(adapters_cls(gpu_model), flavor, gpu_model.embedding_tables(),
+                             AttackConfig(budget=8, sanity_checks=True))
+    res = attack.attack_batch(images.to(DEV), IDS.to(DEV), masks.to(DEV), torch.zeros_like(ATTACKABLE).to(DEV),
+                              dual=True, mlm_labels=labels.to(DEV), init_eta=eta.to(DEV))
+    assert len(res.loss_lists[0]) == 8                                   # 4 iterations x (feature, MLM)
+    for s in range(3):
+        n = int(masks[s].sum()) if flavor == "albef" else IDS.shape[1]
+        ad = ref_cls(cpu_model, IDS[s:s + 1, :n], masks[s:s + 1, :n])
+        targets = ad.gen_ori_feats(images[s:s + 1])
+        lab = labels[s:s + 1, :n]
+        y = [lab, targets[0], targets[1]] if flavor == "albef" else [lab, targets[1], targets[2]]
+        with torch.enable_grad():
+            adv, _ = o.projected_gradient_descent([ad.pgd_attack, ad.pgd_mlm_attack], images[s:s + 1], 0.125, 0.01, 4,
+                                                  np.inf, clip_min=-1, clip_max=1, y=y, ori_x=images[s:s + 1], time=0,
+                                                  ls=0, flavor=flavor, init_eta=eta[s:s + 1])
+        same = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
+        assert same >= 0.99, (flavor, s, same)
