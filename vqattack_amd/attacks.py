@@ -94,9 +94,6 @@ class _LossSlot:
     def __init__(self, buf, index):
         self.word = buf[index:index + 1]
 
-    def scalar(self):
-        return self.word[0]
-
 
 def _feature_pairs(out, y, flavor, vl):
     """(model output, target) row-tensor pairs of the feature loss, after the reference's in-place truncation of
@@ -211,7 +208,8 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             # + 0.1 * CE(labels) + 0.1 * sum over synonym label sets -- all CE terms in ONE fused launch
             sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
             scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
-            _feature_loss_backward([(out[1], y[1]), (out[2], y[2])], slot, leaves, sign, extra_scale=scale,
+            pairs = [(out[2], y[2])] if out[1] is None else [(out[1], y[1]), (out[2], y[2])]
+            _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=scale,
                                    extra=lambda: _ce_backward(out[0], sets, slot, leaves, sign, scale=0.1,
                                                               accumulate=True))
         else:
