@@ -35,6 +35,7 @@ class AlbefConfig:
     mask_id: int = 103
     vit_ln_eps: float = 1e-6
     bert_ln_eps: float = 1e-12
+    weights: str = "trained_like"     # unit-gain synthetic weights, see VlmoConfig.weights
 
     @property
     def n_image_tokens(self):
@@ -144,12 +145,18 @@ class FrozenAlbef(nn.Module):
         def normal_(t):
             t.copy_(torch.empty(t.shape).normal_(0.0, 0.02, generator=g))
 
+        trained = self.cfg.weights == "trained_like"
         with torch.no_grad():
             for mod in self.modules():
-                if isinstance(mod, (nn.Linear, nn.Embedding)):
-                    normal_(mod.weight)
-                    if getattr(mod, "bias", None) is not None:
+                if isinstance(mod, nn.Linear):
+                    if trained:
+                        mod.weight.copy_(torch.empty(mod.weight.shape).normal_(0.0, mod.in_features ** -0.5, generator=g))
+                    else:
+                        normal_(mod.weight)
+                    if mod.bias is not None:
                         mod.bias.zero_()
+                elif isinstance(mod, nn.Embedding):
+                    normal_(mod.weight)
                 elif isinstance(mod, nn.LayerNorm):
                     mod.weight.fill_(1.0)
                     mod.bias.zero_()

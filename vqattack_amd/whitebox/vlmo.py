@@ -41,6 +41,11 @@ class VlmoConfig:
     n_answers: int = 3129
     ln_eps: float = 1e-6
     bert_ln_eps: float = 1e-12
+    # Synthetic weights (no checkpoints offline).  "trained_like": unit-gain linear layers (std = fan_in^-1/2) and layer
+    # scale 1, so activations stay O(1) through the depth and predictions depend on the image, as in a trained network.
+    # "pretrain_init": the reference's initialisation before any training (trunc-normal 0.02, layer scale 0.1) -- with
+    # it every output is dominated by the token embeddings and no perturbation ever changes a black-box answer.
+    weights: str = "trained_like"
 
     @property
     def n_patches(self):
@@ -153,15 +158,25 @@ class FrozenVlmo(nn.Module):
         def normal_(t):
             t.copy_(torch.empty(t.shape).normal_(0.0, 0.02, generator=g))
 
+        trained = self.cfg.weights == "trained_like"
         with torch.no_grad():
             for mod in self.modules():
-                if isinstance(mod, (nn.Linear, nn.Embedding)):
-                    normal_(mod.weight)
-                    if getattr(mod, "bias", None) is not None:
+                if isinstance(mod, nn.Linear):
+                    if trained:
+                        mod.weight.copy_(torch.empty(mod.weight.shape).normal_(0.0, mod.in_features ** -0.5, generator=g))
+                    else:
+                        normal_(mod.weight)
+                    if mod.bias is not None:
                         mod.bias.zero_()
+                elif isinstance(mod, nn.Embedding):
+                    normal_(mod.weight)
                 elif isinstance(mod, nn.LayerNorm):
                     mod.weight.fill_(1.0)
                     mod.bias.zero_()
+            if trained:
+                for blk in self.blocks:
+                    blk.gamma_1.fill_(1.0)
+                    blk.gamma_2.fill_(1.0)
             normal_(self.cls_token)
             normal_(self.mlm_bias)
             normal_(self.rel_pos_bias)
