@@ -252,6 +252,9 @@ _partials = {}
 
 def _partial_buf(device):
     """Per-(device, stream) scratch for the loss partials: launches on one stream are ordered, so reuse is safe."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside hipGraph capture the scratch must live in that graph's private pool: never cache it
+        return torch.empty(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _partials.get(key)
     if buf is None:
