@@ -85,13 +85,18 @@ class BatchedVQAttack:
 
     @torch.no_grad()
     def attack_batch(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, dual=False,
-                     mlm_labels=None, init_eta=None, proposals=None):
+                     mlm_labels=None, init_eta=None, proposals=None, text_ids_mlm=None):
         """Attack one batch whose samples all have the same number of attackable words.
 
         images (B,3,H,W) in [clip_min, clip_max]; text_ids/text_masks (B,L); attackable bool (B,L) with the same
         count per row.  ``mlm_logits_fn(text_ids, text_masks) -> (B,L,V)`` proposes substitution candidates (the
         reference uses a separate HF BERT-MLM, adv_attack.py:110,242; default: the adapters' own ``mlm_logits``);
         ``proposals`` injects them directly (``text_update.propose_candidates`` format).  Returns a ``BatchResult``.
+
+        ``dual=True`` runs the reference's ``old_alg == 0`` blocks (feature step + MLM step per iteration,
+        adv_attack.py:614-619,670-676) with ``mlm_labels`` (B, L) / (B, K, L); ``text_ids_mlm`` is the [MASK]-ed
+        paraphrase the MLM closure reads (``self.batch["text_ids_mlm"]``), kept position-aligned with the question:
+        accepted substitutions are applied to it too, like ``update_mlm_text`` (:334-351).
         """
         c, a = self.cfg, self.adapters
         n_words = int(attackable[0].sum().item())
@@ -102,6 +107,9 @@ class BatchedVQAttack:
         targets = a.gen_ori_feats(images)
         adv = images
         adv_ids = text_ids.clone()
+        mlm_ids = None if text_ids_mlm is None else text_ids_mlm.clone()
+        if mlm_ids is not None:
+            a.set_text(text_ids, text_masks, text_ids_mlm=mlm_ids)
         res = BatchResult(adv_images=adv, adv_text_ids=adv_ids)
         first_time = 0 if c.random_start else 1
         if not blocks:
@@ -122,7 +130,7 @@ class BatchedVQAttack:
             ori_host = text_ids.cpu().numpy()
             positions = list(range(text_ids.shape[1]))
             for bi, steps in enumerate(blocks):
-                a.set_text(adv_ids, text_masks)
+                a.set_text(adv_ids, text_masks, text_ids_mlm=mlm_ids)
                 with torch.enable_grad():
                     adv, losses = self._pgd_block(adv, images, targets, steps, first_time if bi == 0 else 1, dual,
                                                   mlm_labels, init_eta if bi == 0 else None)
@@ -145,5 +153,10 @@ class BatchedVQAttack:
                     changed = [(s, p) for s, per in enumerate(subs) for (p, _, _) in per]
                     if changed:
                         ops.embed_tokens(self.tables, adv_ids, out=adv_emb, rows=changed)
+                        if mlm_ids is not None:      # update_mlm_text: same word replaced in the MLM paraphrase
+                            for s, per in enumerate(subs):
+                                for (p, old, new) in per:
+                                    if int(mlm_ids[s, p]) == old:
+                                        mlm_ids[s, p] = new
         res.adv_images, res.adv_text_ids = adv, adv_ids
         return res

@@ -17,6 +17,27 @@ from .runner import AttackConfig, BatchedVQAttack
 from .schedule import bucket_by_schedule, gradient_steps
 
 
+MASK_ID = 103
+
+
+def synthetic_mlm_task(ids, att, dual_every, seed=0):
+    """Synthetic stand-in for the reference's ``old_alg == 0`` samples (adv_attack.py:433-558: the declarative
+    paraphrase with the answer word [MASK]-ed): every ``dual_every``-th question gets its first body token masked in
+    the MLM text and that token as the only label.  Returns (dual bool (n,), ids_mlm (n, L), labels (n, L))."""
+    n = ids.shape[0]
+    dual = torch.zeros(n, dtype=torch.bool)
+    if dual_every:
+        dual[::dual_every] = True
+    ids_mlm = ids.clone()
+    labels = torch.full_like(ids, -100)
+    for s in torch.nonzero(dual).flatten().tolist():
+        p = 1                                     # first body token ([CLS] is position 0)
+        labels[s, p] = ids[s, p]
+        ids_mlm[s, p] = MASK_ID
+        att[s, p] = False                         # the answer word is not a substitution target
+    return dual, ids_mlm, labels
+
+
 def synthetic_questions(n_samples, text_len, seed=0, min_words=4, max_words=12, joint=True):
     """ids (n, L) int64, masks, attackable (n, L) bool -- on the host (tiny)."""
     r = np.random.RandomState(seed)
@@ -42,13 +63,15 @@ def synthetic_images(qids, image_size, device):
 
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
-              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12):
+              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0):
     """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank."""
     ids, masks, att = synthetic_questions(n_samples, text_len, seed=seed, joint=joint, max_words=max_words)
+    dual, ids_mlm, mlm_labels = synthetic_mlm_task(ids, att, dual_every, seed=seed)
     mine = shard_indices(n_samples, rank, world)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
     ledger = SuccessLedger(world, rank, device)
-    buckets = bucket_by_schedule([int(att[i].sum()) for i in mine])
+    # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg
+    buckets = bucket_by_schedule([int(att[i].sum()) * 2 + int(dual[i]) for i in mine])
     writer = None
     if save_dir:
         from ..preprocess import AdvImageWriter
@@ -57,13 +80,18 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     steps = 0
     done = 0
     t0 = time.perf_counter()
-    for n_words, local in buckets.items():
+    for key, local in buckets.items():
+        n_words, is_dual = key // 2, bool(key % 2)
         for lo in range(0, len(local), batch):
             qids = [mine[j] for j in local[lo:lo + batch]]
             images = synthetic_images(qids, image_size, device)
             tid, tmask, tatt = ids[qids].to(device), masks[qids].to(device), att[qids].to(device)
             clean = black.vqa_answer(images, tid, tmask)
-            res = attack.attack_batch(images, tid, tmask, tatt)
+            if is_dual:
+                res = attack.attack_batch(images, tid, tmask, tatt, dual=True, mlm_labels=mlm_labels[qids].to(device),
+                                          text_ids_mlm=ids_mlm[qids].to(device))
+            else:
+                res = attack.attack_batch(images, tid, tmask, tatt)
             after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
             ledger.record(after != clean, sample_ids=qids)
             steps += res.gradient_steps * len(qids)
