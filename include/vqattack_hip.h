@@ -80,6 +80,11 @@ int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_str
 /* optimize_linear(norm=inf): out = eps * sign(g).  A-ch/utils.py:86,127. */
 int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream);
 
+/* zero_out_clipped_grads: out = (x <= cmin && sign(grad) < 0) || (x >= cmax && sign(grad) > 0) ? 0 : grad.
+ * A-ch/utils.py:131-149 (defined in the reference's utils, unused by its attack drivers). 12 B/element. */
+int vqa_zero_out_clipped_grads(const float* grad, const float* x, float* out, size_t n, float cmin, float cmax,
+                               vqa_stream_t stream);
+
 /* ---------------------------------------------------------------- per-sample reductions (L2 / L1 norms)
  * Deterministic two-stage reductions: stage 1 writes per-block partials into `ws`, stage 2 combines them in a
  * fixed order, so results are bitwise reproducible run to run.  `ws` must hold vqa_reduce_ws_bytes() bytes.

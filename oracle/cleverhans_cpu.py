@@ -87,6 +87,26 @@ def optimize_linear(grad, eps, norm=np.inf):
     return eps * direction
 
 
+def zero_out_clipped_grads(grad, x, clip_min, clip_max):
+    """A-ch/utils.py:131-149."""
+    sg = torch.sign(grad)
+    low = torch.le(x, clip_min) & torch.lt(sg, 0)
+    high = torch.ge(x, clip_max) & torch.gt(sg, 0)
+    return torch.where(low | high, torch.zeros_like(grad), grad)
+
+
+def get_or_guess_labels(model, x, **kwargs):
+    """A-ch/utils.py:43-67."""
+    if "y" in kwargs and "y_target" in kwargs:
+        raise ValueError("Can not set both 'y' and 'y_target'.")
+    if "y" in kwargs:
+        return kwargs["y"]
+    if "y_target" in kwargs and kwargs["y_target"] is not None:
+        return kwargs["y_target"]
+    _, labels = torch.max(model(x), 1)
+    return labels
+
+
 # --------------------------------------------------------------------------- losses
 def _mlm_ce(logits, labels):
     """CE over the MLM vocabulary, 2-d labels or a sum over K label sets (3-d labels).

@@ -16,6 +16,9 @@ class OracleImpl:
     def optimize_linear(self, grad, eps, norm):
         return self.o.optimize_linear(grad, eps, norm)
 
+    def zero_out_clipped_grads(self, grad, x, clip_min, clip_max):
+        return self.o.zero_out_clipped_grads(grad, x, clip_min, clip_max)
+
     def fgm(self, flavor):
         return functools.partial(self.o.fast_gradient_method, flavor=flavor)
 
@@ -42,6 +45,9 @@ class ProductImpl:
 
     def optimize_linear(self, grad, eps, norm):
         return self._load("albef").utils.optimize_linear(grad, eps, norm)
+
+    def zero_out_clipped_grads(self, grad, x, clip_min, clip_max):
+        return self._load("albef").utils.zero_out_clipped_grads(grad, x, clip_min, clip_max)
 
     def fgm(self, flavor):
         return self._load(flavor).fast_gradient_method.fast_gradient_method

@@ -31,6 +31,7 @@ UTIL_CASES = [
     dict(name="optlin_linf", op="optimize_linear", norm="inf", eps=0.01, seed=104),
     dict(name="optlin_l2", op="optimize_linear", norm=2, eps=0.3, seed=105),
     dict(name="optlin_l1", op="optimize_linear", norm=1, eps=1.5, seed=106),
+    dict(name="zero_clipped", op="zero_out_clipped_grads", norm="inf", eps=0.0, seed=107),
 ]
 
 # NB: no case starts a time != 0 run exactly at the clean image: there out == y, the cosine loss sits at its
@@ -150,6 +151,12 @@ def run_case(impl, case, device="cpu"):
     if case["op"] == "optimize_linear":
         t = util_input(case, device)
         return {"out": impl.optimize_linear(t.clone(), case["eps"], norm)}
+    if case["op"] == "zero_out_clipped_grads":
+        g = util_input(case, device)
+        r = np.random.RandomState(case["seed"] + 1)
+        x = torch.from_numpy(r.choice(np.array([-1.0, -0.5, 0.0, 1.0, 1.5, -2.0], dtype=np.float32),
+                                      size=tuple(g.shape))).to(device)
+        return {"out": impl.zero_out_clipped_grads(g, x, -1.0, 1.0)}
 
     toy, x0, start, feats = attack_inputs(case, device)
     flavor = case["flavor"]

@@ -31,7 +31,7 @@ def test_product_matches_reference(case, golden):
         got = val.detach().cpu().numpy()
         assert got.shape == want.shape, key
         tag = (case["name"], key)
-        if case["op"] in ("clip_eta", "optimize_linear"):
+        if case["op"] in ("clip_eta", "optimize_linear", "zero_out_clipped_grads"):
             if case["norm"] == 2:
                 assert np.allclose(got, want, rtol=5e-6, atol=1e-12), tag
             else:

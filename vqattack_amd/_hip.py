@@ -35,6 +35,7 @@ SIGNATURES = {
     "vqa_linf_project": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p]),
     "vqa_clip_eta_linf": (_i, [_p, _p, _sz, _f, _p]),
     "vqa_optimize_linear_linf": (_i, [_p, _p, _sz, _f, _p]),
+    "vqa_zero_out_clipped_grads": (_i, [_p, _p, _p, _sz, _f, _f, _p]),
     "vqa_reduce_ws_bytes": (_sz, [_i, _sz]),
     "vqa_sumsq_per_sample": (_i, [_p, _p, _p, _i, _sz, _p, _p]),
     "vqa_absmax_ties_per_sample": (_i, [_p, _p, _p, _i, _sz, _p, _p]),

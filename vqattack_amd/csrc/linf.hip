@@ -72,6 +72,15 @@ struct ClipEtaOp {
     return clamp_torch(eta, -p.eps, p.eps);
   }
 };
+struct ZeroClippedOp {   // zero_out_clipped_grads: stream 0 = grad, stream 1 = x
+  static constexpr int kIn = 2;
+  __device__ static float apply(const StepParams& p, float g, float x, float, bool&) {
+    const float sg = sign_torch(g);
+    const bool low = (x <= p.cmin) && (sg < 0.0f);
+    const bool high = (x >= p.cmax) && (sg > 0.0f);
+    return (low || high) ? 0.0f : g;
+  }
+};
 struct SignScaleOp {
   static constexpr int kIn = 1;
   __device__ static float apply(const StepParams& p, float g, float, float, bool&) {
@@ -150,7 +159,8 @@ static void launch_vec(int nt, int grid, hipStream_t st, const f32x4* a0, const 
   }
 }
 
-template <class Op, bool TUNABLE = false>
+// NTMASK restricts the non-temporal hints an op may use: bit0 only makes sense when the second stream is read once.
+template <class Op, bool TUNABLE = false, int NTMASK = 3>
 static int launch_stream(const float* s0, const float* s1, const float* s2, float* out, size_t n,
                          const StepParams& p, int* flag, vqa_stream_t stream) {
   if (!s0 || !out || (Op::kIn > 1 && !s1) || (Op::kIn > 2 && !s2)) return VQA_ERR_NULL;
@@ -174,9 +184,9 @@ static int launch_stream(const float* s0, const float* s1, const float* s2, floa
     auto a1 = reinterpret_cast<const f32x4*>(s1);
     auto a2 = reinterpret_cast<const f32x4*>(s2);
     auto o = reinterpret_cast<f32x4*>(out);
-    if (TUNABLE && unroll == 2) launch_vec<Op, 2>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
-    else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
-    else launch_vec<Op, 4>(g_opt_nontemporal, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    if (TUNABLE && unroll == 2) launch_vec<Op, 2>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else launch_vec<Op, 4>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
     done = n4 * 4;
   }
   if (done < n) {
@@ -239,12 +249,18 @@ int vqa_linf_step(const float* x, const float* g, const float* x0, float* out, s
 int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, float eps, float cmin,
                      float cmax, unsigned mode, vqa_stream_t stream) {
   StepParams p{0.0f, eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
-  return launch_stream<ProjectOp>(adv, x0, nullptr, out, n, p, nullptr, stream);
+  return launch_stream<ProjectOp, false, 2>(adv, x0, nullptr, out, n, p, nullptr, stream);   // x0 is re-read every step
 }
 
 int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream) {
   StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
   return launch_stream<ClipEtaOp>(eta, nullptr, nullptr, out, n, p, nullptr, stream);
+}
+
+int vqa_zero_out_clipped_grads(const float* grad, const float* x, float* out, size_t n, float cmin, float cmax,
+                               vqa_stream_t stream) {
+  StepParams p{0.0f, 0.0f, cmin, cmax, 0u};
+  return launch_stream<ZeroClippedOp, false, 2>(grad, x, nullptr, out, n, p, nullptr, stream);   // x is not read-once
 }
 
 int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream) {

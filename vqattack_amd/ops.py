@@ -136,6 +136,19 @@ def optimize_linear_linf(grad, eps):
     return out
 
 
+def zero_out_clipped_grads(grad, x, clip_min, clip_max):
+    dev_f32(grad, "grad"), dev_f32(x, "x")
+    if grad.shape != x.shape:
+        raise ValueError("grad shape {} != x shape {}".format(tuple(grad.shape), tuple(x.shape)))
+    out = torch.empty_like(grad)
+    if grad.numel() == 0:
+        return out
+    with _on(grad):
+        check(lib().vqa_zero_out_clipped_grads(ptr(grad), ptr(x), ptr(out), grad.numel(), float(clip_min),
+                                               float(clip_max), stream_for(grad)), "vqa_zero_out_clipped_grads")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- per-sample norms
 def _per_sample(t):
     batch = t.shape[0] if t.dim() > 0 else 1

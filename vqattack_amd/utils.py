@@ -47,3 +47,22 @@ def optimize_linear(grad, eps, norm=np.inf):
         g = _device_tensor(grad, "grad")
         return ops.scale_per_sample(g, ops.sumsq_per_sample(g), None, eps, kind=1)
     raise NotImplementedError("Only L-inf, L1 and L2 norms are currently implemented.")
+
+
+def zero_out_clipped_grads(grad, x, clip_min, clip_max):
+    """Erase gradient entries whose update would be clipped away (x at a bound and the gradient pointing outwards).
+    Reference: utils.py:131-149 (defined there, not called by the attack drivers)."""
+    return ops.zero_out_clipped_grads(_device_tensor(grad, "grad"), _device_tensor(x, "x"), clip_min, clip_max)
+
+
+def get_or_guess_labels(model, x, **kwargs):
+    """Labels for crafting an adversarial example: ``y`` (untargeted), ``y_target`` (targeted) or the model's own
+    prediction.  Reference: utils.py:43-67 (host logic; unused by the attack drivers)."""
+    if "y" in kwargs and "y_target" in kwargs:
+        raise ValueError("Can not set both 'y' and 'y_target'.")
+    if "y" in kwargs:
+        return kwargs["y"]
+    if kwargs.get("y_target") is not None:
+        return kwargs["y_target"]
+    _, labels = torch.max(model(x), 1)
+    return labels
