@@ -259,7 +259,7 @@ int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int
   ce_count_kernel<<<K, kBlock, 0, st>>>(labels, rows, ignore_index, inv_count);
   const int grid = static_cast<int>(rows);
   // register path: row_stride == V keeps the gradient row's alignment phase equal to the logits row's
-  const bool reg_path = V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
+  const bool reg_path = V >= 8 && V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
   if (reg_path) {
 #define VQA_CE_REG(G, T) \
   ce_rows_reg_kernel<G, 8, T><<<grid, T, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count, \
