@@ -403,3 +403,22 @@ def test_empty_inputs_are_no_ops():
     ga = ops.neg_cos_rows(torch.empty(0, 5, 16, device=DEV), torch.empty(0, 5, 16, device=DEV), slot, accumulate=False)
     assert ga.shape == (0, 5, 16) and float(slot) == 0.0
     assert ops.gather_rows(torch.empty(0, 4, 16, device=DEV), [1, 2]).shape == (0, 2, 16)
+
+
+@pytest.mark.parametrize("v", [1000, 7, 33334, 30523], ids=str)
+def test_mlm_cross_entropy_other_vocabularies(v):
+    """Vocabulary sizes off the register-resident fast path (tiny, larger than one workgroup's registers, odd)."""
+    import torch.nn.functional as F
+    ops = _ops()
+    r = np.random.RandomState(29)
+    rows = 9
+    logits = torch.from_numpy((r.standard_normal((rows, v)) * 2).astype(np.float32))
+    labels = torch.from_numpy(r.randint(0, v, (2, rows)))
+    labels[0, ::2] = -100
+    a = logits.clone().requires_grad_(True)
+    want = sum(F.cross_entropy(a, labels[i], ignore_index=-100) for i in range(2))
+    want.backward()
+    slot = torch.zeros(1, device=DEV)
+    g = ops.mlm_cross_entropy(logits.to(DEV), labels.to(DEV), slot, accumulate=False)
+    assert torch.allclose(slot.cpu()[0], want.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(g.cpu(), a.grad, rtol=1e-4, atol=1e-7)
