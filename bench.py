@@ -77,7 +77,7 @@ def build_models(args, cfg, device):
     if args.model.startswith("albef"):
         from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef
         white = FrozenAlbef(cfg, seed=0).to(device)
-        black = FrozenAlbef(cfg, seed=1, vqa_head=True).to(device)
+        black = FrozenAlbef.finetuned_from(white, seed=1).to(device)
         return "albef", white, black, AlbefAttackAdapters(white), (8 if args.model == "albef_tiny" else 40)
     from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters
     white = FrozenVlmo(cfg, seed=0).to(device)

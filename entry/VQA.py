@@ -28,7 +28,7 @@ def main():
     from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_base, albef_tiny
     mcfg = albef_tiny() if args.tiny else albef_base(image_size=cfg["image_res"])
     white = FrozenAlbef(mcfg, seed=args.seed).to(device)
-    black = FrozenAlbef(mcfg, seed=args.seed + 1, vqa_head=True).to(device)
+    black = FrozenAlbef.finetuned_from(white, seed=args.seed + 1).to(device)
     out_dir = os.path.join(args.output_dir, cfg.get("attack_dir", "attack_dir")) if args.output_dir else None
     res = run_sweep("albef", white, black, AlbefAttackAdapters(white), args.n_samples or cfg["n_samples"],
                     cfg["batch_size_test"], mcfg.image_size, min(cfg["text_len"], 8 if args.tiny else 512), device,

@@ -49,7 +49,7 @@ def main():
     mcfg = vlmo.vlmo_tiny() if cfg["arch"] == "vlmo_tiny" else getattr(vlmo, cfg["arch"])(
         image_size=cfg["image_size"], max_text_len=cfg["max_text_len"])
     white = vlmo.FrozenVlmo(mcfg, seed=cfg["seed"]).to(device)
-    black = vlmo.FrozenVlmo(mcfg, seed=cfg["seed"] + 1, vqa_head=True).to(device)
+    black = vlmo.FrozenVlmo.finetuned_from(white, seed=cfg["seed"] + 1).to(device)
     res = run_sweep("vlmo", white, black, vlmo.VlmoAttackAdapters(white), cfg["n_samples"], cfg["per_gpu_batchsize"],
                     mcfg.image_size, mcfg.max_text_len, device, rank, world, joint=not cfg["image_only"],
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],

@@ -22,7 +22,7 @@ def test_sweep_tiny(flavor, tmp_path):
         from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_tiny
         cfg = albef_tiny()
         white = FrozenAlbef(cfg, seed=0).to(DEV)
-        black = FrozenAlbef(cfg, seed=1, vqa_head=True).to(DEV)
+        black = FrozenAlbef.finetuned_from(white, seed=1).to(DEV)
         adapters, text_len = AlbefAttackAdapters(white), 8
     res = run_sweep(flavor, white, black, adapters, n_samples=11, batch=4, image_size=cfg.image_size,
                     text_len=text_len, device=DEV, config=AttackConfig(budget=8, sim_threshold=0.2),

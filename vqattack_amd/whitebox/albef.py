@@ -36,6 +36,11 @@ class AlbefConfig:
     vit_ln_eps: float = 1e-6
     bert_ln_eps: float = 1e-12
     weights: str = "trained_like"     # unit-gain synthetic weights, see VlmoConfig.weights
+    decoder_depth: int = 6            # answer decoder of the VQA model (model_vqa.py:30-33: 6 layers, fusion_layer 0)
+    k_test: int = 128                 # configs/VQA.yaml
+    answer_len: int = 5               # [BOS] + up to 3 word pieces + [SEP], padded
+    bos_id: int = 1
+    sep_id: int = 102
 
     @property
     def n_image_tokens(self):
@@ -50,7 +55,7 @@ def albef_tiny(**kw):
     # vit_depth == bert_depth: the reference's loss adds the per-row sums of the two modalities elementwise
     # (fast_gradient_method.py:127), which only works when both encoders return the same number of layers (13 / 13)
     return AlbefConfig(dim=64, vit_depth=3, bert_depth=3, fusion_layer=1, heads=4, patch=8, image_size=32,
-                       n_answers=13, **kw)
+                       n_answers=13, decoder_depth=2, k_test=5, **kw)
 
 
 class _Mlp(nn.Module):
@@ -106,10 +111,10 @@ class _BertLayer(nn.Module):
         self.ln_cross = nn.LayerNorm(d, eps=e) if cross else None
         self.mlp, self.ln_out = _Mlp(d, 4 * d), nn.LayerNorm(d, eps=e)
 
-    def forward(self, x, self_mask, image_states):
+    def forward(self, x, self_mask, image_states, cross_mask=None):
         x = self.ln_attn(x + self.attn(x, x, self_mask))
         if self.cross is not None:
-            x = self.ln_cross(x + self.cross(x, image_states))
+            x = self.ln_cross(x + self.cross(x, image_states, cross_mask))
         return self.ln_out(x + self.mlp(x))
 
 
@@ -131,8 +136,27 @@ class FrozenAlbef(nn.Module):
         self.mlm_dense = nn.Linear(d, d)
         self.mlm_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
         self.mlm_bias = nn.Parameter(torch.zeros(cfg.vocab))
-        self.vqa_classifier = nn.Sequential(nn.Linear(d, 2 * d), nn.GELU(), nn.Linear(2 * d, cfg.n_answers)) \
-            if vqa_head else None
+        # VQA victim (model_vqa.py): the fused text encoder's states are read by a 6-layer causal BERT decoder with
+        # cross-attention in every layer and its own embeddings + LM head; answers are RANKED, not classified
+        self.has_vqa = vqa_head
+        if vqa_head:
+            self.dec_word = nn.Embedding(cfg.vocab, d)
+            self.dec_pos = nn.Embedding(cfg.max_position, d)
+            self.dec_type = nn.Embedding(2, d)
+            self.dec_emb_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+            self.dec_layers = nn.ModuleList([_BertLayer(cfg, True) for _ in range(cfg.decoder_depth)])
+            self.dec_dense = nn.Linear(d, d)
+            self.dec_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
+            self.dec_bias = nn.Parameter(torch.zeros(cfg.vocab))
+            g = torch.Generator().manual_seed(seed + 4242)
+            n_tok = torch.randint(1, cfg.answer_len - 1, (cfg.n_answers,), generator=g)        # 1..answer_len-2 pieces
+            ans = torch.zeros(cfg.n_answers, cfg.answer_len, dtype=torch.long)
+            ans[:, 0] = cfg.bos_id
+            body = torch.randint(1000, cfg.vocab, (cfg.n_answers, cfg.answer_len), generator=g)
+            for i in range(cfg.n_answers):
+                ans[i, 1:1 + n_tok[i]] = body[i, :n_tok[i]]
+                ans[i, 1 + n_tok[i]] = cfg.sep_id
+            self.register_buffer("answer_ids", ans, persistent=False)                          # synthetic answer list
         self._mask_gen = None
         self._init(seed)
         self.eval()
@@ -163,6 +187,22 @@ class FrozenAlbef(nn.Module):
             normal_(self.cls_token)
             normal_(self.pos_embed)
             normal_(self.mlm_bias)
+
+    @classmethod
+    def finetuned_from(cls, white, seed=1, drift=0.25):
+        """Synthetic VQA victim: the white box's encoders after fine-tuning (every shared weight moved by ``drift`` of
+        its RMS) plus a freshly initialised answer decoder -- the reference's VQA checkpoint is the pre-trained ALBEF
+        fine-tuned on VQA (``adv_attack.py:83-100`` loads the two checkpoints into the two models)."""
+        black = cls(white.cfg, seed=seed, vqa_head=True)
+        g = torch.Generator().manual_seed(seed + 7919)
+        src = dict(white.named_parameters())
+        with torch.no_grad():
+            for name, p in black.named_parameters():
+                if name in src:
+                    w = src[name].detach().cpu()
+                    rms = float(w.pow(2).mean().sqrt())
+                    p.copy_(w + drift * rms * torch.empty(w.shape).normal_(generator=g))
+        return black
 
     # ---- pieces ---------------------------------------------------------------------------------------------
     def visual_encoder(self, image):
@@ -243,15 +283,60 @@ class FrozenAlbef(nn.Module):
         states, _ = self.text_encoder(self.text_embeddings(self.mask_tokens(text_ids)), text_masks, image_states)
         return self.mlm_head(states)
 
+    # ---- black-box VQA scorer: batched rank_answer (model_vqa.py:149-203) ----------------------------------------
+    def _decode(self, ids, atts, question_states, question_atts):
+        """Causal decoder pass; returns LM logits (n, L, V)."""
+        n, length = ids.shape
+        e = self.dec_word(ids) + self.dec_type.weight[0]
+        e = self.dec_emb_ln(e + self.dec_pos.weight[:length].unsqueeze(0))
+        causal = torch.ones(length, length, dtype=torch.bool, device=ids.device).tril()
+        keep = causal[None, None] & atts.bool()[:, None, None, :]
+        self_mask = torch.zeros(n, 1, length, length, device=ids.device).masked_fill(~keep, float("-inf"))
+        cross_mask = torch.zeros(n, 1, 1, question_atts.shape[1], device=ids.device).masked_fill(
+            ~question_atts.bool()[:, None, None, :], float("-inf"))
+        x = e
+        for layer in self.dec_layers:
+            x = layer(x, self_mask, question_states, cross_mask)
+        h = self.dec_ln(F.gelu(self.dec_dense(x)))
+        return F.linear(h, self.dec_word.weight, self.dec_bias)
+
+    @torch.no_grad()
+    def rank_answer(self, question_states, question_atts, k=None):
+        """Top-k answers per question, re-ranked by the full-sequence LM likelihood; returns (topk_ids, topk_probs),
+        both (B, k), sorted by probability.  Batched restatement of model_vqa.py:149-203 (no per-question loop)."""
+        cfg = self.cfg
+        k = min(k or cfg.k_test, cfg.n_answers)
+        b = question_states.shape[0]
+        ans, ans_atts = self.answer_ids, (self.answer_ids != cfg.pad_id).long()
+        start = ans[0, 0].repeat(b, 1)                                               # [BOS]
+        logits = self._decode(start, torch.ones_like(start), question_states, question_atts)[:, 0, :]
+        prob_first = F.softmax(logits, dim=1).index_select(dim=1, index=ans[:, 1])   # P(first answer token)
+        topk_probs, topk_ids = prob_first.topk(k, dim=1)
+        ids = ans[topk_ids].reshape(b * k, -1)                                       # (B*k, L)
+        atts = ans_atts[topk_ids].reshape(b * k, -1)
+        targets = ids.masked_fill(ids == cfg.pad_id, -100)
+        q_states = question_states.repeat_interleave(k, dim=0)
+        q_atts = question_atts.repeat_interleave(k, dim=0)
+        lm = self._decode(ids, atts, q_states, q_atts)
+        # BertLMHeadModel loss with reduction='none' (xbert.py:1265-1271): shift, per-token CE, sum over the sequence
+        tok = F.cross_entropy(lm[:, :-1, :].reshape(-1, cfg.vocab), targets[:, 1:].reshape(-1), reduction="none",
+                              ignore_index=-100)
+        answer_loss = tok.view(b * k, -1).sum(1, keepdim=True)
+        log_probs = torch.cat([topk_probs.view(-1, 1).log(), -answer_loss], dim=1).sum(1).view(b, k)
+        probs = F.softmax(log_probs, dim=-1)
+        probs, rerank = probs.topk(k, dim=1)
+        return torch.gather(topk_ids, 1, rerank), probs
+
     @torch.no_grad()
     def vqa_answer(self, image, text_ids, text_masks):
-        """Black-box stand-in: answer = argmax of a classifier on the fused [CLS] state.  (The reference's black box
-        ranks 128 candidate answers with a text decoder, models/model_vqa.py:149-203 -- a 'next' row)"""
-        if self.vqa_classifier is None:
-            raise RuntimeError("this FrozenAlbef was built without a VQA head")
+        """Black-box prediction = index (into the answer list) of the best re-ranked answer
+        (adv_attack.py:722-726: ``_, pred = topk_prob.max(dim=0); answer_list[topk_id[pred]]``)."""
+        if not self.has_vqa:
+            raise RuntimeError("this FrozenAlbef was built without the VQA decoder")
         image_states, _ = self.visual_encoder(image)
         states, _ = self.text_encoder(self.text_embeddings(text_ids), text_masks, image_states)
-        return self.vqa_classifier(states[:, 0]).argmax(dim=-1)
+        topk_ids, _ = self.rank_answer(states, text_masks)
+        return topk_ids[:, 0]
 
 
 class AlbefAttackAdapters:
