@@ -50,6 +50,16 @@ def main():
     g = torch.randn(shape, device="cuda", generator=gen)
     out = torch.empty_like(x)
     report("vqa_linf_step", 16 * n, timeit(lambda: ops.linf_step(x, g, x0, 0.01, 0.125, -1, 1, out=out)))
+    def eager_chain():
+        # the reference's op chain between two model calls, as PyTorch-ROCm runs it (SURVEY.md section 2.3, rows 1-13
+        # without the host sync): range flags, clone, sign, scale, add, clamp, sub, clamp, add, clamp
+        torch.all(torch.ge(x, -1.0)), torch.all(torch.le(x, 1.0))
+        xc = x.clone()
+        a = torch.clamp(xc + 0.01 * torch.sign(g), -1, 1)
+        eta = torch.clamp(a - x0, -0.125, 0.125)
+        return torch.clamp(x0 + eta, -1, 1)
+    report("reference eager chain on the GPU (13 ATen ops), same 16 B/el basis", 16 * n, timeit(eager_chain),
+           "what vqa_linf_step replaces; moves ~92 B/element")
     report("vqa_linf_fgm", 12 * n, timeit(lambda: ops.linf_fgm(x, g, 0.01, -1, 1, out=out)))
     report("vqa_linf_init (eta)", 12 * n, timeit(lambda: ops.linf_init(x0, eta, 0.125, -1, 1, out=out)))
     report("vqa_linf_init (zero)", 8 * n, timeit(lambda: ops.linf_init(x0, None, 0.125, -1, 1, out=out)))
