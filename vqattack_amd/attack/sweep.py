@@ -6,7 +6,6 @@ optionally save ``<qid>.pt`` (``adv_attack.py:714``), score with the black box, 
 Offline there are no VQAv2 images, tokenizer or checkpoints, so samples are synthetic:
 images U(-1,1), questions ``[CLS] body [SEP] pad`` with 4..12 body tokens, all body tokens single-piece words.
 """
-import os
 import time
 
 import numpy as np

@@ -15,7 +15,6 @@ Differences from the reference that serve the MI355X design (none changes a sing
   * attention goes through ``F.scaled_dot_product_attention`` with the relative-position bias and key-padding mask
     folded into one additive mask.
 """
-import math
 from dataclasses import dataclass
 
 import torch
