@@ -30,3 +30,23 @@ def test_graphed_pgd_equals_eager(batch):
     with pytest.raises(ValueError):
         vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 2.0, 0.5, 2, 2, y=list(y), graph=True,
                                                 clip_min=-1, clip_max=1, ori_x=x0, time=1, ls=1, flavor="vlmo")
+
+
+def test_runner_with_graph_replay_equals_eager():
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny
+    cfg = vlmo_tiny()
+    model = FrozenVlmo(cfg, seed=6).to(DEV)
+    ids = torch.tensor([[101, 2054, 3609, 2003, 102, 0, 0, 0], [101, 2129, 2116, 6077, 102, 0, 0, 0]], device=DEV)
+    masks = (ids != 0).long()
+    g = torch.Generator().manual_seed(8)
+    img = torch.empty(2, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g).to(DEV)
+    eta = torch.empty(img.shape).uniform_(-0.125, 0.125, generator=g).to(DEV)
+    none = torch.zeros_like(ids, dtype=torch.bool)
+    outs = []
+    for use_graph in (False, True):
+        atk = BatchedVQAttack(VlmoAttackAdapters(model), "vlmo", model.embedding_tables(),
+                              AttackConfig(budget=9, use_graph=use_graph))
+        outs.append(atk.attack_batch(img, ids, masks, none, init_eta=eta))
+    assert torch.equal(outs[0].adv_images, outs[1].adv_images)
+    assert outs[0].loss_lists == outs[1].loss_lists
