@@ -18,7 +18,7 @@ NAMED = {
     "tiny": dict(arch="vlmo_tiny", image_size=32, max_text_len=8),
 }
 DEFAULTS = dict(arch="vlmo_base", image_size=384, max_text_len=40, per_gpu_batchsize=64, seed=1, test_only=True,
-                n_samples=128, image_only=False, attack_dir="", dual_every=0)
+                n_samples=128, image_only=False, attack_dir="", dual_every=0, mixed=False)
 
 
 def parse(argv):
@@ -53,7 +53,7 @@ def main():
     res = run_sweep("vlmo", white, black, vlmo.VlmoAttackAdapters(white), cfg["n_samples"], cfg["per_gpu_batchsize"],
                     mcfg.image_size, mcfg.max_text_len, device, rank, world, joint=not cfg["image_only"],
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],
-                    max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"])
+                    max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"])
     finish(rank, world, res)
 
 

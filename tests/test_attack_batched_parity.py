@@ -126,3 +126,35 @@ def test_batched_dual_loss_attack_matches_per_sample_oracle(flavor):
                                                   ls=0, flavor=flavor, init_eta=eta[s:s + 1])
         same = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
         assert same >= 0.99, (flavor, s, same)
+
+
+@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
+def test_mixed_schedule_batch_matches_per_sample_oracle(flavor):
+    """One batch, three different schedules (0, 2 and 3 substitutable words): prefix scheduling must give every sample the
+    result of its own batch-1 attack."""
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    cpu_model, gpu_model, adapters_cls, ref_cls, cfg = _build(flavor)
+    g = torch.Generator().manual_seed(31)
+    images = torch.empty(3, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(images).uniform_(-0.125, 0.125, generator=g)
+    masks = (IDS != 0).long()
+    att = torch.zeros_like(ATTACKABLE)
+    att[1, [1, 2, 4]] = True                      # sample 1: three words, sample 2: two, sample 0: none
+    att[2, [1, 2]] = True
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(adapters_cls(gpu_model), flavor, gpu_model.embedding_tables(),
+                             AttackConfig(budget=10, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    logits = attack.adapters.mlm_logits(IDS.to(DEV), masks.to(DEV))
+    proposals = text_update.propose_candidates(logits, IDS, att, threshold=0)
+    res = attack.attack_mixed(images.to(DEV), IDS.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    assert res.gradient_steps == 10 + 13 + 12
+    for s in range(3):
+        n = int(masks[s].sum()) if flavor == "albef" else IDS.shape[1]
+        adv, ids, _ = attack_loop.attack_one(ref_cls, cpu_model, flavor, images[s:s + 1], IDS[s:s + 1, :n],
+                                             masks[s:s + 1, :n], proposals[s] if proposals[s] else None, sim,
+                                             init_eta=eta[s:s + 1], budget=10, sim_threshold=0.3)
+        same = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
+        assert same >= 0.99, (flavor, s, same)
+        assert res.adv_text_ids[s, :n].cpu().tolist() == ids[0].tolist(), (flavor, s)
+    assert (res.adv_text_ids.cpu() != IDS).sum().item() >= 1

@@ -8,8 +8,9 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
+@pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("flavor", ["vlmo", "albef"])
-def test_sweep_tiny(flavor, tmp_path):
+def test_sweep_tiny(flavor, mixed, tmp_path):
     from vqattack_amd.attack.runner import AttackConfig
     from vqattack_amd.attack.sweep import run_sweep
     if flavor == "vlmo":
@@ -26,7 +27,7 @@ def test_sweep_tiny(flavor, tmp_path):
         adapters, text_len = AlbefAttackAdapters(white), 8
     res = run_sweep(flavor, white, black, adapters, n_samples=11, batch=4, image_size=cfg.image_size,
                     text_len=text_len, device=DEV, config=AttackConfig(budget=8, sim_threshold=0.2),
-                    save_dir=str(tmp_path), log_every=0, max_words=3, dual_every=3)
+                    save_dir=str(tmp_path), log_every=0, max_words=3, dual_every=3, mixed=mixed)
     assert res["n_total"] == 11 and res["n_local"] == 11
     assert 0.0 <= res["asr"] <= 1.0
     assert sorted(map(int, res["adv_text"])) == list(range(11))

@@ -21,7 +21,8 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from .. import dropin, ops
+from .. import attacks, dropin, ops
+from ..features import LayerFeatures
 from . import text_update
 from .schedule import IMAGE_STEP_BUDGET, iter_schedule
 
@@ -159,4 +160,92 @@ class BatchedVQAttack:
                                     if int(mlm_ids[s, p]) == old:
                                         mlm_ids[s, p] = new
         res.adv_images, res.adv_text_ids = adv, adv_ids
+        return res
+
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def attack_mixed(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, init_eta=None,
+                     proposals=None):
+        """Feature-loss joint attack of a batch whose samples have DIFFERENT numbers of attackable words.
+
+        A sample with ``w`` substitutable words is, end to end, one sequence of ``budget + w`` L-inf steps whose text
+        changes after each of its probe steps (the reference's per-block ``projected_gradient_descent`` calls restart
+        from a feasible point with eta = 0, which is a no-op).  So the batch runs ``max(budget + w)`` global steps;
+        samples are sorted by length so that the still-active ones are always a batch PREFIX (finished samples drop out
+        of the white-box batch instead of being masked), every step takes the image+text-embedding gradient, and a
+        sample's word substitution fires right after its own probe steps.  Per-sample results equal ``attack_batch`` on
+        schedule-pure buckets (tests/test_attack_batched_parity.py).
+        """
+        c, a = self.cfg, self.adapters
+        if c.norm != np.inf:
+            raise ValueError("attack_mixed implements the L-inf feature-loss attack")
+        dev, b, length = images.device, images.shape[0], text_ids.shape[1]
+        n_words = attackable.sum(dim=1).tolist()
+        total = [c.budget + int(w) for w in n_words]
+        order = sorted(range(b), key=lambda s: -total[s])                 # longest first: active set = prefix
+        perm = torch.tensor(order, device=dev)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(b, device=dev)
+        images, text_ids, text_masks, attackable = images[perm], text_ids[perm], text_masks[perm], attackable[perm]
+        if init_eta is not None:
+            init_eta = init_eta[perm]
+        total = [total[s] for s in order]
+        probes = []                                                       # per sample: global step indices of its probes
+        for s in order:
+            blocks, at, mine = iter_schedule(int(n_words[s]), c.budget), 0, set()
+            for j, blen in enumerate(blocks[:-1]):
+                at += blen
+                mine.add(at + j)
+            probes.append(mine)
+        if proposals is None:
+            fn = mlm_logits_fn or getattr(a, "mlm_logits", None)
+            proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
+                                                       banned=self.banned_ids) if fn is not None else [[] for _ in range(b)]
+        else:
+            proposals = [proposals[s] for s in order]
+        a.set_text(text_ids, text_masks)
+        pinned = getattr(a, "_tlen", None)                                # token layout of the targets
+        targets = a.gen_ori_feats(images)
+        e_ori = ops.embed_tokens(self.tables, text_ids)
+        adv_emb = e_ori.clone()
+        adv_ids = text_ids.clone()
+        ori_host = text_ids.cpu().numpy()
+        flag = ops.new_flag(dev)
+        eta = init_eta
+        if eta is None and c.random_start:
+            eta = torch.empty_like(images).uniform_(-c.eps, c.eps)
+        cur = ops.linf_init(images.contiguous(), eta, c.eps, c.clip_min, c.clip_max, flag=flag)
+        losses = torch.zeros(max(total), dtype=torch.float32, device=dev)
+        res = BatchResult(adv_images=cur, adv_text_ids=adv_ids)
+        n_act_prev = None
+        for t in range(max(total)):
+            n_act = sum(1 for x in total if x > t)
+            if n_act != n_act_prev:
+                a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
+                y = [v.rows(n_act) if isinstance(v, LayerFeatures) else (None if v is None else v[:n_act])
+                     for v in self._y_feature(targets)]
+                n_act_prev = n_act
+            leaf_img = cur[:n_act].detach().requires_grad_(True)
+            leaf_txt = adv_emb[:n_act].detach().requires_grad_(True)
+            attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1, self.flavor,
+                                   False, attacks._LossSlot(losses, t), vl=True)
+            ops.linf_step(cur[:n_act], leaf_img.grad, images[:n_act], c.eps_iter, c.eps, c.clip_min, c.clip_max,
+                          out=cur[:n_act])                                # in place: finished samples stay untouched
+            firing = [s for s in range(n_act) if t in probes[s]]
+            if firing:
+                props = [proposals[s] if s in firing else [] for s in range(n_act)]
+                cand, scores = text_update.score_candidates(self.tables, e_ori[:n_act], leaf_txt.grad, props)
+                new_ids, subs = text_update.greedy_accept(cand, scores, ori_host[:n_act], adv_ids[:n_act].cpu().numpy(),
+                                                          self.similarity_fn, c.sim_threshold)
+                changed = [(s, p) for s, per in enumerate(subs) for (p, _, _) in per]
+                if changed:
+                    adv_ids[:n_act] = torch.as_tensor(new_ids, device=dev, dtype=adv_ids.dtype)
+                    ops.embed_tokens(self.tables, adv_ids, out=adv_emb, rows=changed)
+                    a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
+                res.substitutions.append(subs)
+        if c.sanity_checks:
+            assert int(flag.item()) == 0, "input images are outside [clip_min, clip_max]"
+        res.adv_images, res.adv_text_ids = cur[inv], adv_ids[inv]
+        res.loss_lists = [losses.tolist()]
+        res.gradient_steps = sum(total)
         return res

@@ -62,15 +62,21 @@ def synthetic_images(qids, image_size, device):
 
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
-              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0):
-    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank."""
+              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False):
+    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank.
+
+    ``mixed=False``: samples are bucketed by (schedule, loss mode) and every batch is schedule-pure
+    (``BatchedVQAttack.attack_batch``).  ``mixed=True``: feature-loss samples are batched in index order whatever their
+    word counts (``attack_mixed``, prefix scheduling); dual-loss samples still go through their buckets."""
     ids, masks, att = synthetic_questions(n_samples, text_len, seed=seed, joint=joint, max_words=max_words)
     dual, ids_mlm, mlm_labels = synthetic_mlm_task(ids, att, dual_every, seed=seed)
     mine = shard_indices(n_samples, rank, world)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
     ledger = SuccessLedger(world, rank, device)
-    # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg
-    buckets = bucket_by_schedule([int(att[i].sum()) * 2 + int(dual[i]) for i in mine])
+    # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg;
+    # with mixed=True all feature-loss samples share ONE bucket (key -2) and are scheduled per sample inside the batch
+    buckets = bucket_by_schedule([(-2 if (mixed and not dual[i]) else int(att[i].sum()) * 2 + int(dual[i]))
+                                  for i in mine])
     writer = None
     if save_dir:
         from ..preprocess import AdvImageWriter
@@ -86,15 +92,18 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             images = synthetic_images(qids, image_size, device)
             tid, tmask, tatt = ids[qids].to(device), masks[qids].to(device), att[qids].to(device)
             clean = black.vqa_answer(images, tid, tmask)
-            if is_dual:
+            if key == -2:
+                res = attack.attack_mixed(images, tid, tmask, tatt)
+            elif is_dual:
                 res = attack.attack_batch(images, tid, tmask, tatt, dual=True, mlm_labels=mlm_labels[qids].to(device),
                                           text_ids_mlm=ids_mlm[qids].to(device))
             else:
                 res = attack.attack_batch(images, tid, tmask, tatt)
             after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
             ledger.record(after != clean, sample_ids=qids)
-            steps += res.gradient_steps * len(qids)
-            assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget)
+            steps += res.gradient_steps * (1 if key == -2 else len(qids))
+            if key != -2:
+                assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget) * len(qids) // len(qids)
             for q, row in zip(qids, res.adv_text_ids.cpu().tolist()):
                 adv_text[str(q)] = row
             if writer is not None:

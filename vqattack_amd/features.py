@@ -54,6 +54,11 @@ class LayerFeatures:
             return LayerFeatures([t[:, :n, :] for t in self.layers], w)
         raise IndexError("LayerFeatures supports only [:, :n, :]")
 
+    def rows(self, n):
+        """The first ``n`` samples of every layer (views) -- a batch prefix, for schedules where samples finish early."""
+        w = None if self.row_weight is None else self.row_weight[:n].contiguous()
+        return LayerFeatures([t[:n] for t in self.layers], w)
+
     def detach(self):
         return LayerFeatures([t.detach() for t in self.layers], self.row_weight)
 

@@ -346,7 +346,8 @@ class AlbefAttackAdapters:
         self.model = model
         self.batch = {}
 
-    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
+    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None, text_len=None):
+        self._tlen = text_ids.shape[1]          # no trimming here: the caller passes the text at its own length
         self.batch["text_ids"], self.batch["text_masks"] = text_ids, text_masks
         self.batch["text_ids_mlm"] = text_ids if text_ids_mlm is None else text_ids_mlm
         self.batch["text_mask_mlm"] = text_masks if text_mask_mlm is None else text_mask_mlm

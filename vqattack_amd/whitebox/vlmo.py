@@ -312,8 +312,10 @@ class VlmoAttackAdapters:
         prefix = bool((m == (torch.arange(full, device=m.device)[None, :] < lengths[:, None])).all())
         return max(int(lengths.max()), 1) if prefix else full       # one host sync per text batch
 
-    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
-        n = self._text_len(text_masks if text_mask_mlm is None else (text_masks | text_mask_mlm))
+    def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None, text_len=None):
+        """``text_len`` pins the trimmed text length (callers that change the batch between ``gen_ori_feats`` and the
+        attack steps must keep the token layout of the targets)."""
+        n = text_len or self._text_len(text_masks if text_mask_mlm is None else (text_masks | text_mask_mlm))
         self._tlen = n
         self.batch["text_ids"], self.batch["text_masks"] = text_ids[:, :n], text_masks[:, :n]
         self.batch["text_ids_mlm"] = self.batch["text_ids"] if text_ids_mlm is None else text_ids_mlm[:, :n]
