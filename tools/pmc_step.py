@@ -26,3 +26,15 @@ slot = torch.zeros(1, device="cuda")
 for _ in range(3):
     ops.neg_cos_rows(a, b, slot, accumulate=False)
 torch.cuda.synchronize()
+
+# MLM cross entropy at the B=64 shape (2560 rows x 30522) and the per-sample reductions of the L2 path
+logits = torch.randn(64 * 40, 30522, device="cuda")
+labels = torch.randint(0, 30522, (1, 64 * 40), device="cuda")
+for _ in range(3):
+    ops.mlm_cross_entropy(logits, labels, slot, accumulate=False)
+torch.cuda.synchronize()
+del logits
+g = torch.randn(64, 3, 384, 384, device="cuda")
+for _ in range(3):
+    ops.sumsq_per_sample(g)
+torch.cuda.synchronize()
