@@ -42,7 +42,7 @@ const char* vqa_error_string(int code);
  *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1)
  *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
  *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup
- *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 1024) */
+ *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 256) */
 int vqa_set_option(int option, int value);
 
 /* ---------------------------------------------------------------- L-infinity image update (hot)

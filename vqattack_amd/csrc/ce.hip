@@ -132,10 +132,14 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
 // on this chip, MI355X_MICROARCH.md).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
-static int g_ce_threads = 1024;       // vqa_set_option(4, 256 | 512 | 1024)
+static int g_ce_threads = 256;        // vqa_set_option(4, 256 | 512 | 1024); 256 measured fastest at 2 WG/CU
+
+// launch bounds: two workgroups per CU whatever THREADS is (2 * THREADS / 256 waves per SIMD), so that one row's
+// reduce/exp phase overlaps the other's HBM phase; that caps the kernel at 64 VGPRs for THREADS = 1024
+constexpr int ce_blocks_per_cu(int) { return 2; }   // 3 per CU forces spills at 256 threads: 181 us vs 130 us
 
 template <bool GRAD, int MAXK, int THREADS>
-__global__ __launch_bounds__(THREADS) void ce_rows_reg_kernel(const float* __restrict__ logits, long row_stride,
+__global__ __launch_bounds__(THREADS, ce_blocks_per_cu(THREADS) * THREADS / 256) void ce_rows_reg_kernel(const float* __restrict__ logits, long row_stride,
                                                              const int64_t* __restrict__ labels, int K, long rows,
                                                              int V, long ignore_index,
                                                              const float* __restrict__ inv_count,
@@ -261,12 +265,15 @@ int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int
   // register path: row_stride == V keeps the gradient row's alignment phase equal to the logits row's
   const bool reg_path = V >= 8 && V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
   if (reg_path) {
-#define VQA_CE_REG(G, T) \
-  ce_rows_reg_kernel<G, 8, T><<<grid, T, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count, \
-                                                  grad, row_loss, gscale)
-    if (g_ce_threads == 256) { if (grad) VQA_CE_REG(true, 256); else VQA_CE_REG(false, 256); }
-    else if (g_ce_threads == 512) { if (grad) VQA_CE_REG(true, 512); else VQA_CE_REG(false, 512); }
-    else { if (grad) VQA_CE_REG(true, 1024); else VQA_CE_REG(false, 1024); }
+#define VQA_CE_REG(G, MK, T) \
+  ce_rows_reg_kernel<G, MK, T><<<grid, T, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count, \
+                                                   grad, row_loss, gscale)
+#define VQA_CE_K(G, T) \
+  do { if (K == 1) VQA_CE_REG(G, 1, T); else if (K <= 4) VQA_CE_REG(G, 4, T); else VQA_CE_REG(G, 8, T); } while (0)
+    if (g_ce_threads == 256) { if (grad) VQA_CE_K(true, 256); else VQA_CE_K(false, 256); }
+    else if (g_ce_threads == 512) { if (grad) VQA_CE_K(true, 512); else VQA_CE_K(false, 512); }
+    else { if (grad) VQA_CE_K(true, 1024); else VQA_CE_K(false, 1024); }
+#undef VQA_CE_K
 #undef VQA_CE_REG
     return launch_status();
   }
