@@ -50,3 +50,24 @@ def test_runner_with_graph_replay_equals_eager():
         outs.append(atk.attack_batch(img, ids, masks, none, init_eta=eta))
     assert torch.equal(outs[0].adv_images, outs[1].adv_images)
     assert outs[0].loss_lists == outs[1].loss_lists
+
+
+def test_patch_layout_state_equals_image_layout():
+    """The PGD state kept patch-major (layout.py) gives bit-identical adversarial images."""
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny
+    cfg = vlmo_tiny()
+    model = FrozenVlmo(cfg, seed=6).to(DEV)
+    ids = torch.tensor([[101, 2054, 3609, 2003, 102, 0, 0, 0], [101, 2129, 2116, 6077, 102, 0, 0, 0]], device=DEV)
+    masks = (ids != 0).long()
+    g = torch.Generator().manual_seed(9)
+    img = torch.empty(2, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g).to(DEV)
+    eta = torch.empty(img.shape).uniform_(-0.125, 0.125, generator=g).to(DEV)
+    none = torch.zeros_like(ids, dtype=torch.bool)
+    outs = []
+    for patch_layout in (False, True):
+        atk = BatchedVQAttack(VlmoAttackAdapters(model), "vlmo", model.embedding_tables(),
+                              AttackConfig(budget=7, patch_layout=patch_layout, sanity_checks=True))
+        outs.append(atk.attack_batch(img, ids, masks, none, init_eta=eta))
+    assert outs[1].adv_images.shape == img.shape
+    assert torch.equal(outs[0].adv_images, outs[1].adv_images)

@@ -21,7 +21,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from .. import attacks, dropin, ops
+from .. import attacks, dropin, layout, ops
 from ..features import LayerFeatures
 from . import text_update
 from .schedule import IMAGE_STEP_BUDGET, iter_schedule
@@ -39,6 +39,7 @@ class AttackConfig:
     sanity_checks: bool = False        # the flag read is a host sync; parity tests switch it on
     sim_threshold: float = text_update.SIM_THRESHOLD   # adv_attack.py:303
     use_graph: bool = False            # replay PGD iterations from a hipGraph (small, launch-bound batches)
+    patch_layout: bool = False         # keep the PGD state patch-major (layout.py); measured neutral end to end, see DESIGN
 
 
 @dataclass
@@ -104,6 +105,7 @@ class BatchedVQAttack:
         if not bool((attackable.sum(dim=1) == n_words).all()):
             raise ValueError("samples of one batch must share a schedule: bucket them with bucket_by_schedule()")
         blocks = iter_schedule(n_words, c.budget)
+        images, init_eta, restore = self._enter_layout(images, init_eta)
         a.set_text(text_ids, text_masks)
         targets = a.gen_ori_feats(images)
         adv = images
@@ -159,8 +161,18 @@ class BatchedVQAttack:
                                 for (p, old, new) in per:
                                     if int(mlm_ids[s, p]) == old:
                                         mlm_ids[s, p] = new
-        res.adv_images, res.adv_text_ids = adv, adv_ids
+        res.adv_images, res.adv_text_ids = restore(adv), adv_ids
         return res
+
+    def _enter_layout(self, images, init_eta):
+        """Switch the PGD state to patch-major layout when enabled and supported by the white box (its config names a
+        patch size); returns (images, init_eta, restore) with ``restore`` mapping the result back to (B, 3, H, W)."""
+        patch = getattr(getattr(getattr(self.adapters, "model", None), "cfg", None), "patch", None)
+        if not self.cfg.patch_layout or patch is None or images.dim() != 4:
+            return images, init_eta, (lambda t: t)
+        _, ch, h, w = images.shape
+        eta = None if init_eta is None else layout.to_patches(init_eta, patch)
+        return layout.to_patches(images, patch), eta, (lambda t: layout.from_patches(t, patch, h, w, ch))
 
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -179,7 +191,8 @@ class BatchedVQAttack:
         c, a = self.cfg, self.adapters
         if c.norm != np.inf:
             raise ValueError("attack_mixed implements the L-inf feature-loss attack")
-        dev, b, length = images.device, images.shape[0], text_ids.shape[1]
+        dev, b = images.device, images.shape[0]
+        images, init_eta, restore = self._enter_layout(images, init_eta)
         n_words = attackable.sum(dim=1).tolist()
         total = [c.budget + int(w) for w in n_words]
         order = sorted(range(b), key=lambda s: -total[s])                 # longest first: active set = prefix
@@ -245,7 +258,7 @@ class BatchedVQAttack:
                 res.substitutions.append(subs)
         if c.sanity_checks:
             assert int(flag.item()) == 0, "input images are outside [clip_min, clip_max]"
-        res.adv_images, res.adv_text_ids = cur[inv], adv_ids[inv]
+        res.adv_images, res.adv_text_ids = restore(cur[inv]), adv_ids[inv]
         res.loss_lists = [losses.tolist()]
         res.gradient_steps = sum(total)
         return res

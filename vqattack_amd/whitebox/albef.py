@@ -206,9 +206,11 @@ class FrozenAlbef(nn.Module):
 
     # ---- pieces ---------------------------------------------------------------------------------------------
     def visual_encoder(self, image):
+        """``image``: (B, 3, H, W), or already patch-major (B, n_patches, 3*p*p) (``vqattack_amd.layout``)."""
         b, p = image.shape[0], self.cfg.patch
         g = self.cfg.image_size // p
-        patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+        patches = image if image.dim() == 3 else \
+            image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
         x = torch.cat([self.cls_token.expand(b, -1, -1), self.patch_proj(patches)], dim=1) + self.pos_embed
         feats = [x]
         for blk in self.vit_blocks:
