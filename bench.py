@@ -246,13 +246,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # any torchrun launch, also N = 1
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the attack path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal mode: VQA_DIST_BACKEND=gloo lets several ranks share one GPU (collectives then run on host tensors);
+    # the driver's multi-GPU runs use the default, RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("VQA_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
 
     from vqattack_amd.attack.asr import SuccessLedger
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
@@ -261,7 +269,7 @@ def main():
     flavor, white, black, adapters, text_len = build_models(args, cfg, device)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
-    ledger = SuccessLedger(world, rank, device, force_collective=use_dist)
+    ledger = SuccessLedger(world, rank, coll_device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     images = torch.empty(args.batch, 3, cfg.image_size, cfg.image_size, device=device).uniform_(-1, 1, generator=gen)
@@ -300,7 +308,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.remove()
     if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     roof, roof_loss = timer.summary()
