@@ -102,7 +102,7 @@ class KernelTimer:
 
     def install(self):
         from vqattack_amd import ops
-        self._step, self._loss = ops.linf_step, ops.neg_cos_rows
+        self._step, self._loss = ops.linf_step, ops.neg_cos_rows_multi
         timer = self
 
         def timed_step(x, *a, **kw):
@@ -114,26 +114,27 @@ class KernelTimer:
             timer.step_numel = x.numel()
             return out
 
-        def timed_loss(a_, b_, *a, **kw):
+        def timed_loss(a_list, b_list, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = timer._loss(a_, b_, *a, **kw)
+            out = timer._loss(a_list, b_list, *a, **kw)
             e1.record()
             timer.loss_events.append((e0, e1))
             w = kw.get("row_weight")
+            a_ = a_list[0]
             rows = a_.numel() // a_.shape[-1]
             if w is not None:                 # live (weight != 0) rows; one host read per distinct weight plane
                 key = (w.data_ptr(), w.numel())
                 if key not in timer._live:
                     timer._live[key] = int((w != 0).sum().item())
                 rows = timer._live[key] * (rows // w.numel())
-            timer.loss_bytes.append((12 if out is not None else 8) * rows * a_.shape[-1])
+            timer.loss_bytes.append((12 if out is not None else 8) * rows * a_.shape[-1] * len(a_list))
             return out
-        ops.linf_step, ops.neg_cos_rows = timed_step, timed_loss
+        ops.linf_step, ops.neg_cos_rows_multi = timed_step, timed_loss
 
     def remove(self):
         from vqattack_amd import ops
-        ops.linf_step, ops.neg_cos_rows = self._step, self._loss
+        ops.linf_step, ops.neg_cos_rows_multi = self._step, self._loss
 
     @staticmethod
     def _stats(events):
@@ -158,7 +159,7 @@ class KernelTimer:
         if n:
             total_bytes = sum(self.loss_bytes)           # launches differ in size (text / image rows): bytes over time
             gbs = total_bytes / (mean_ms * n) / 1e6
-            loss = dict(kernel="vqa_neg_cos_rows (+ vqa_sum_partials)", bound="hbm", achieved=round(gbs, 1),
+            loss = dict(kernel="vqa_neg_cos_rows_multi (+ vqa_sum_partials), all layers of a modality per launch", bound="hbm", achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
                         algorithmic_bytes_per_launch=round(total_bytes / n),

@@ -146,6 +146,17 @@ int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, 
                      long b_stride0, long b_stride1, long g_stride0, long g_stride1, float gscale,
                      float cos_eps, vqa_stream_t stream);
 
+/* The same pass over n_layers <= vqa_neg_cos_max_layers() feature maps of identical shape and strides in ONE launch
+ * (the 13 / 25 per-layer maps of an encoder, never packed into one tensor): a, b, ga are HOST arrays of n_layers device
+ * base pointers, copied into the kernel arguments (capture-safe); ga == NULL -> loss only.  Replaces the reference's
+ * torch.cat / torch.stack feature packing (ALBEF_attack/adv_attack.py:124-125, vlmo_module.py:1435-1444) together
+ * with the loss ops listed above.  Algorithmic bytes: n_layers * rows * 12*D (8*D without the gradient). */
+int vqa_neg_cos_max_layers(void);
+int vqa_neg_cos_rows_multi(const float* const* a, const float* const* b, float* const* ga, int n_layers,
+                           float* partial, const uint8_t* row_mask, long mask_period, long rows0, long rows1, int D,
+                           long a_stride0, long a_stride1, long b_stride0, long b_stride1, long g_stride0,
+                           long g_stride1, float gscale, float cos_eps, vqa_stream_t stream);
+
 /* dst[0] = (accumulate ? dst[0] : 0) + scale * sum_{i<count} partial[i], summed in index order by one workgroup.
  * Turns the partials of one or more vqa_neg_cos_rows launches into the scalar loss on the device
  * (the reference's float(loss.cpu()) host sync per step, projected_gradient_descent.py:145, is deferred). */

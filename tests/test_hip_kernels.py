@@ -422,3 +422,31 @@ def test_mlm_cross_entropy_other_vocabularies(v):
     g = ops.mlm_cross_entropy(logits.to(DEV), labels.to(DEV), slot, accumulate=False)
     assert torch.allclose(slot.cpu()[0], want.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(g.cpu(), a.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_neg_cos_rows_multi_equals_per_layer_launches():
+    ops = _ops()
+    r = np.random.RandomState(30)
+    layers = 5
+    a = [torch.from_numpy(r.standard_normal((3, 17, 64)).astype(np.float32)).to(DEV) for _ in range(layers)]
+    b = [torch.from_numpy(r.standard_normal((3, 17, 64)).astype(np.float32)).to(DEV) for _ in range(layers)]
+    w = torch.from_numpy((r.uniform(size=(3, 17)) > 0.2).astype(np.uint8)).to(DEV)
+    w[:, 0] = 2
+    one, many = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    g_one = [ops.neg_cos_rows(a[i], b[i], one, accumulate=i > 0, gscale=0.5, row_weight=w, weight_period=3)
+             for i in range(layers)]
+    g_many = ops.neg_cos_rows_multi(a, b, many, accumulate=False, gscale=0.5, row_weight=w, weight_period=3)
+    assert len(g_many) == layers
+    for x, y in zip(g_one, g_many):
+        assert torch.equal(x, y)                                   # same arithmetic per row
+    assert torch.allclose(one, many, rtol=1e-6, atol=1e-5)        # partial sums are grouped differently
+    # loss only, and the non-uniform fallback (one layer is a strided view with different strides)
+    ops.neg_cos_rows_multi(a, b, many, accumulate=True, gscale=-0.5, want_grad=False, row_weight=w, weight_period=3)
+    assert abs(float(many)) <= 1e-4
+    big = torch.zeros(3, 20, 64, device=DEV)
+    big[:, :17] = a[2]
+    a_mixed = list(a)
+    a_mixed[2] = big[:, :17]
+    g_fb = ops.neg_cos_rows_multi(a_mixed, b, many, accumulate=False, gscale=0.5, row_weight=w, weight_period=3)
+    for x, y in zip(g_one, g_fb):
+        assert torch.equal(x, y)

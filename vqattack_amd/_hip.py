@@ -45,6 +45,8 @@ SIGNATURES = {
     "vqa_scale_per_sample": (_i, [_p, _p, _p, _p, _i, _sz, _f, _i, _p]),
     "vqa_neg_cos_partials": (_i, []),
     "vqa_neg_cos_rows": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p]),
+    "vqa_neg_cos_max_layers": (_i, []),
+    "vqa_neg_cos_rows_multi": (_i, [_p, _p, _p, _i, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p]),
     "vqa_sum_partials": (_i, [_p, _i, _p, _i, _f, _p]),
     "vqa_ce_max_label_sets": (_i, []),
     "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _p, _p, _p, _f, _p]),

@@ -124,20 +124,30 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=Non
     """
     tensors, grads = [], []
     gscale = sign * extra_scale
-    launches = [trip for (o, t) in pairs for trip in layer_pairs(o, t)]   # one launch per (layer, modality)
-    for k, (o, t, w) in enumerate(launches):
-        if not o.is_cuda or not t.is_cuda:
-            raise HipExtensionError("model_fn outputs and targets y must be on the HIP device")
-        o32 = o if o.dtype == torch.float32 else o.to(torch.float32)
-        t32 = t.detach() if t.dtype == torch.float32 else t.detach().to(torch.float32)
+    first = True
+    for (o_pair, t_pair) in pairs:
+        trips = layer_pairs(o_pair, t_pair)                 # per-layer (out, target, row weight)
+        outs, tgts = [], []
+        for (o, t, _) in trips:
+            if not o.is_cuda or not t.is_cuda:
+                raise HipExtensionError("model_fn outputs and targets y must be on the HIP device")
+            outs.append(o if o.dtype == torch.float32 else o.to(torch.float32))
+            tgts.append(t.detach() if t.dtype == torch.float32 else t.detach().to(torch.float32))
+        w = trips[0][2]
+        period = outs[0].shape[0] if w is not None else 1
         # layers that do not depend on a leaf (ALBEF text states below the fusion layer during image-only steps)
         # still contribute their constant to the loss value, but need no gradient pass
-        needs_grad = o32.requires_grad
-        ga = ops.neg_cos_rows(o32.detach(), t32, slot.word, accumulate=(k > 0), gscale=gscale, want_grad=needs_grad,
-                              row_weight=w, weight_period=(o32.shape[0] if w is not None else 1))
-        if needs_grad:
-            tensors.append(o32)
-            grads.append(ga)
+        for needs_grad in (True, False):
+            idx = [i for i, o in enumerate(outs) if o.requires_grad == needs_grad]
+            if not idx:
+                continue
+            ga = ops.neg_cos_rows_multi([outs[i].detach() for i in idx], [tgts[i] for i in idx], slot.word,
+                                        accumulate=not first, gscale=gscale, want_grad=needs_grad, row_weight=w,
+                                        weight_period=period)      # ONE launch for all layers of this modality
+            first = False
+            if needs_grad:
+                tensors += [outs[i] for i in idx]
+                grads += ga
     if extra is not None:
         more_t, more_g = extra()
         tensors += more_t

@@ -23,20 +23,34 @@ struct RowAddr {
   long mask_period;
 };
 
+// Up to kMaxLayers (a, b, grad) base pointers passed BY VALUE in the kernel arguments: one launch covers every
+// per-layer feature map of a LayerFeatures list (13 for the base encoders, 25 for VLMo-large) without packing them.
+constexpr int kMaxLayers = 32;
+struct LayerTable {
+  const float* a[kMaxLayers];
+  const float* b[kMaxLayers];
+  float* g[kMaxLayers];
+  int n;
+};
+
 template <int NCH, bool GRAD>
-__global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(const float* __restrict__ a,
-                                                              const float* __restrict__ b,
-                                                              float* __restrict__ ga,
-                                                              float* __restrict__ partial,
+__global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(LayerTable tab, float* __restrict__ partial,
                                                               const uint8_t* __restrict__ row_mask, RowAddr ra,
                                                               int D, float gscale, float cos_eps) {
   __shared__ float lds[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const long total = ra.rows0 * ra.rows1;
+  const long per_layer = ra.rows0 * ra.rows1;
+  const long total = per_layer * tab.n;
   const long wstride = static_cast<long>(gridDim.x) * kWavesPerBlock;
   float acc = 0.0f;   // this wave's sum of -cos over its rows (same value in every lane)
-  for (long r = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave; r < total; r += wstride) {
+  for (long rr = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave; rr < total; rr += wstride) {
+    // wave-uniform by construction; readfirstlane makes it a scalar so the table lookup is one s_load, not a waterfall
+    const int layer = __builtin_amdgcn_readfirstlane(static_cast<int>(rr / per_layer));
+    const long r = rr - layer * per_layer;
+    const float* __restrict__ a = tab.a[layer];
+    const float* __restrict__ b = tab.b[layer];
+    float* __restrict__ ga = tab.g[layer];
     const long o = r / ra.rows1, i = r - o * ra.rows1;
     const float w = row_mask ? static_cast<float>(row_mask[(o % ra.mask_period) * ra.rows1 + i]) : 1.0f;
     const bool live = w != 0.0f;   // wave-uniform: weight-0 rows (padded tokens) are never loaded
@@ -126,12 +140,29 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __res
 }
 
 template <int NCH>
-static void launch_cos(bool grad, int grid, hipStream_t st, const float* a, const float* b, float* ga,
-                       float* partial, const uint8_t* mask, const RowAddr& ra, int D, float gscale, float eps) {
+static void launch_cos(bool grad, int grid, hipStream_t st, const LayerTable& tab, float* partial,
+                       const uint8_t* mask, const RowAddr& ra, int D, float gscale, float eps) {
   if (grad)
-    neg_cos_rows_kernel<NCH, true><<<grid, kBlock, 0, st>>>(a, b, ga, partial, mask, ra, D, gscale, eps);
+    neg_cos_rows_kernel<NCH, true><<<grid, kBlock, 0, st>>>(tab, partial, mask, ra, D, gscale, eps);
   else
-    neg_cos_rows_kernel<NCH, false><<<grid, kBlock, 0, st>>>(a, b, ga, partial, mask, ra, D, gscale, eps);
+    neg_cos_rows_kernel<NCH, false><<<grid, kBlock, 0, st>>>(tab, partial, mask, ra, D, gscale, eps);
+}
+
+static int launch_cos_table(const LayerTable& tab, bool grad, float* partial, const uint8_t* row_mask,
+                            const RowAddr& ra, int D, float gscale, float cos_eps, hipStream_t st) {
+  // always launch the full grid: every partial slot is (re)written, so vqa_sum_partials can fold a fixed count
+  const int grid = kLossBlocks;
+  switch ((D + 255) / 256) {
+    case 1: launch_cos<1>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 2: launch_cos<2>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 3: launch_cos<3>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 4: launch_cos<4>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 5: launch_cos<5>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 6: launch_cos<6>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    case 7: launch_cos<7>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+    default: launch_cos<8>(grad, grid, st, tab, partial, row_mask, ra, D, gscale, cos_eps); break;
+  }
+  return launch_status();
 }
 
 }  // namespace vqa
@@ -156,21 +187,40 @@ int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, 
   RowAddr ra{rows0, rows1 > 0 ? rows1 : 1, a_stride0, a_stride1, b_stride0, b_stride1, g_stride0, g_stride1,
              row_mask ? mask_period : 1};
   if (rows1 == 0) ra.rows0 = 0;
-  // always launch the full grid: every partial slot is (re)written, so vqa_sum_partials can fold a fixed count
-  const int grid = kLossBlocks;
-  const int nch = (D + 255) / 256;
-  const bool grad = ga != nullptr;
-  switch (nch) {
-    case 1: launch_cos<1>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 2: launch_cos<2>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 3: launch_cos<3>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 4: launch_cos<4>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 5: launch_cos<5>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 6: launch_cos<6>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    case 7: launch_cos<7>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
-    default: launch_cos<8>(grad, grid, st, a, b, ga, partial, row_mask, ra, D, gscale, cos_eps); break;
+  LayerTable tab{};
+  tab.a[0] = a;
+  tab.b[0] = b;
+  tab.g[0] = ga;
+  tab.n = 1;
+  return launch_cos_table(tab, ga != nullptr, partial, row_mask, ra, D, gscale, cos_eps, st);
+}
+
+int vqa_neg_cos_max_layers(void) { return kMaxLayers; }
+
+int vqa_neg_cos_rows_multi(const float* const* a, const float* const* b, float* const* ga, int n_layers,
+                           float* partial, const uint8_t* row_mask, long mask_period, long rows0, long rows1, int D,
+                           long a_stride0, long a_stride1, long b_stride0, long b_stride1, long g_stride0,
+                           long g_stride1, float gscale, float cos_eps, vqa_stream_t stream) {
+  if (!a || !b || !partial) return VQA_ERR_NULL;
+  if (n_layers < 1 || n_layers > kMaxLayers) return VQA_ERR_SHAPE;
+  if (rows0 < 0 || rows1 < 0 || D <= 0 || D > 2048 || (D & 3)) return VQA_ERR_SHAPE;
+  if ((a_stride0 | a_stride1 | b_stride0 | b_stride1) & 3) return VQA_ERR_SHAPE;
+  if (ga && ((g_stride0 | g_stride1) & 3)) return VQA_ERR_SHAPE;
+  if (row_mask && mask_period <= 0) return VQA_ERR_SHAPE;
+  LayerTable tab{};
+  tab.n = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!a[l] || !b[l] || (ga && !ga[l])) return VQA_ERR_NULL;
+    if (!aligned16(a[l]) || !aligned16(b[l]) || (ga && !aligned16(ga[l]))) return VQA_ERR_ALIGN;
+    tab.a[l] = a[l];
+    tab.b[l] = b[l];
+    tab.g[l] = ga ? ga[l] : nullptr;
   }
-  return launch_status();
+  RowAddr ra{rows0, rows1 > 0 ? rows1 : 1, a_stride0, a_stride1, b_stride0, b_stride1, g_stride0, g_stride1,
+             row_mask ? mask_period : 1};
+  if (rows1 == 0) ra.rows0 = 0;
+  return launch_cos_table(tab, ga != nullptr, partial, row_mask, ra, D, gscale, cos_eps,
+                          static_cast<hipStream_t>(stream));
 }
 
 int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,

@@ -344,6 +344,51 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
     return ga
 
 
+def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None,
+                       weight_period=1):
+    """``neg_cos_rows`` over a list of same-shaped feature maps in ONE launch; returns the list of gradients (views of
+    one ``(L, ...)`` buffer) or None.  Falls back to per-map launches when the maps do not share shape and strides."""
+    n = len(a_list)
+    if n != len(b_list) or n == 0:
+        raise ValueError("need as many targets as feature maps")
+    a0, b0 = a_list[0], b_list[0]
+    uniform = (n <= lib().vqa_neg_cos_max_layers() and a0.numel() > 0 and
+               all(t.shape == a0.shape and t.stride() == a0.stride() and t.dtype == torch.float32 and t.is_cuda and
+                   _kernel_ready(t) for t in a_list) and
+               all(t.shape == a0.shape and t.stride() == b0.stride() and t.dtype == torch.float32 and t.is_cuda and
+                   _kernel_ready(t) for t in b_list) and a0.shape[-1] % 4 == 0 and a0.shape[-1] <= 2048)
+    if not uniform or n == 1:
+        grads = []
+        for k, (a, b) in enumerate(zip(a_list, b_list)):
+            grads.append(neg_cos_rows(a, b, loss_out, accumulate or k > 0, gscale, want_grad, row_weight, weight_period))
+        return grads if want_grad else None
+    r0, r1, d, sa0, sa1 = _rows_view(a0, "out")
+    _, _, _, sb0, sb1 = _rows_view(b0, "y")
+    ga = None
+    g0 = g1 = 0
+    if want_grad:
+        ga = torch.empty((n,) + tuple(a0.shape), dtype=torch.float32, device=a0.device)
+        _, _, _, g0, g1 = _rows_view(ga[0], "grad")
+    if row_weight is not None:
+        if row_weight.dtype != torch.uint8 or not row_weight.is_cuda or not row_weight.is_contiguous():
+            raise TypeError("row_weight must be a contiguous uint8 device tensor")
+        if row_weight.numel() != weight_period * r1:
+            raise ValueError("row_weight has {} entries, expected weight_period*rows1 = {}".format(
+                row_weight.numel(), weight_period * r1))
+    arr = ctypes.c_void_p * n
+    pa = arr(*[t.data_ptr() for t in a_list])
+    pb = arr(*[t.data_ptr() for t in b_list])
+    pg = arr(*[ga[i].data_ptr() for i in range(n)]) if want_grad else None
+    part = _partial_buf(a0.device)
+    with _on(a0):
+        st = stream_for(a0)
+        check(lib().vqa_neg_cos_rows_multi(pa, pb, pg, n, ptr(part), ptr(row_weight), weight_period, r0, r1, d, sa0, sa1,
+                                           sb0, sb1, g0, g1, gscale, _COS_EPS, st), "vqa_neg_cos_rows_multi")
+        check(lib().vqa_sum_partials(ptr(part), part.numel(), ptr(loss_out), 1 if accumulate else 0, gscale, st),
+              "vqa_sum_partials")
+    return [ga[i] for i in range(n)] if want_grad else None
+
+
 def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want_grad=True, ignore_index=-100):
     """loss_out[0] (+)= gscale * sum_k CE_mean(logits, label_sets[k]); returns d(that)/d logits or None.
 
