@@ -33,6 +33,9 @@ typedef void* vqa_stream_t; /* a hipStream_t (NULL = the legacy default stream) 
 #define VQA_CHECK_RANGE 2u    /* atomically OR 1 into *flag when an INPUT x element is outside [cmin, cmax] or NaN
                                  (reference: torch.all(ge(x, clip_min)) / le(x, clip_max) sanity flags,
                                  A-ch/attacks/projected_gradient_descent.py:95-105) */
+/* further bits the kernels may OR into a *flag word */
+#define VQA_FLAG_RANGE 1      /* set by VQA_CHECK_RANGE */
+#define VQA_FLAG_BAD_LABEL 2  /* vqa_ce_rows: a label is neither ignore_index nor in [0, V) (torch device-asserts) */
 
 int vqa_abi_version(void);
 const char* vqa_error_string(int code);
@@ -42,7 +45,13 @@ const char* vqa_error_string(int code);
  *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1)
  *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
  *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup
- *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 256) */
+ *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 256)
+ *   option 5: workgroups of the cross-entropy kernel resident per CU (2 = default, 3 = tighter register budget)
+ *   option 6: grid of the cosine-loss kernel, 0 = exactly the resident workgroups (occupancy x CUs, default),
+ *             n = 1..8 workgroups per CU
+ *   option 7: rows in flight per wavefront in the cosine-loss kernel (1 or 2; default 2)
+ *   option 8: non-temporal hints of the cosine-loss kernel, bit0 = loads of `a`, bit1 = gradient stores, bit2 = loads
+ *             of the targets `b` (default 4) */
 int vqa_set_option(int option, int value);
 
 /* ---------------------------------------------------------------- L-infinity image update (hot)
@@ -138,13 +147,19 @@ int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, 
  * A-ch/attacks/fast_gradient_method.py:98,120-127; V-ch/attacks/fast_gradient_method.py:102-114.
  * D must be a multiple of 4 and <= 2048; a, b, ga 16-byte aligned with strides multiples of 4.
  * Algorithmic bytes: 8*D per row (loss only) or 12*D per row (loss + gradient).
- * `partial` must hold vqa_neg_cos_partials() floats.
+ * `partial` must hold vqa_neg_cos_partials() floats: one slot per workgroup plus the arrival counter of the in-kernel
+ * fold, which must be ZERO before the first launch that uses the buffer (the folding workgroup resets it; launches that
+ * share a buffer must be ordered on one stream).
+ * loss_out (nullable): the workgroup that arrives last folds the partials in index order and writes
+ *   loss_out[0] = (accumulate ? loss_out[0] : 0) + gscale * sum(partial)      -- bitwise reproducible, no second launch.
+ * loss_out == NULL: partials only; fold them with vqa_sum_partials(partial, vqa_neg_cos_partials(), ...).
+ * The grid is the number of workgroups resident at once (occupancy x compute units, queried from the device).
  */
 int vqa_neg_cos_partials(void);
 int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, const uint8_t* row_mask,
                      long mask_period, long rows0, long rows1, int D, long a_stride0, long a_stride1,
                      long b_stride0, long b_stride1, long g_stride0, long g_stride1, float gscale,
-                     float cos_eps, vqa_stream_t stream);
+                     float cos_eps, float* loss_out, int accumulate, vqa_stream_t stream);
 
 /* The same pass over n_layers <= vqa_neg_cos_max_layers() feature maps of identical shape and strides in ONE launch
  * (the 13 / 25 per-layer maps of an encoder, never packed into one tensor): a, b, ga are HOST arrays of n_layers device
@@ -155,7 +170,8 @@ int vqa_neg_cos_max_layers(void);
 int vqa_neg_cos_rows_multi(const float* const* a, const float* const* b, float* const* ga, int n_layers,
                            float* partial, const uint8_t* row_mask, long mask_period, long rows0, long rows1, int D,
                            long a_stride0, long a_stride1, long b_stride0, long b_stride1, long g_stride0,
-                           long g_stride1, float gscale, float cos_eps, vqa_stream_t stream);
+                           long g_stride1, float gscale, float cos_eps, float* loss_out, int accumulate,
+                           vqa_stream_t stream);
 
 /* dst[0] = (accumulate ? dst[0] : 0) + scale * sum_{i<count} partial[i], summed in index order by one workgroup.
  * Turns the partials of one or more vqa_neg_cos_rows launches into the scalar loss on the device
@@ -165,16 +181,22 @@ int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate
 
 /* Masked-LM cross entropy with ignore_index over K label sets, loss and gradient in one launch:
  *   loss = sum_k mean_{r : labels[k][r] != ignore} ( logsumexp(logits[r,:]) - logits[r, labels[k][r]] )
- * row_loss[r] receives row r's share (fold it with vqa_sum_partials(row_loss, rows, dst, acc, gscale));
+ * row_loss[r] (scratch, `rows` floats) receives row r's share; loss_out (nullable) receives
+ *   loss_out[0] = (accumulate ? loss_out[0] : 0) + gscale * sum_r row_loss[r]      (summed in row order, in the launch);
  * grad (nullable, (rows, V) contiguous) receives gscale * d loss / d logits.  labels is int64 [K][rows];
- * inv_count is a K-float scratch the launch fills with 1/n_valid_k.  K <= vqa_ce_max_label_sets().
+ * scratch holds vqa_ce_scratch_floats() floats (reciprocal valid counts + the fold's arrival counter; the launch
+ * initialises it).  K <= vqa_ce_max_label_sets().
+ * A label that is neither ignore_index nor in [0, V) makes the loss NaN and ORs VQA_FLAG_BAD_LABEL into *flag
+ * (flag nullable); torch raises a device assert for it, it is never silently ignored.
+ * exp() is the hardware exponential (v_exp_f32, ~2 ulp); parity with torch is stated as 1e-4 relative in the tests.
  * Replaces F.cross_entropy(out[0].view(-1, 30522), y[0][...].view(-1), ignore_index=-100), its K-fold repetition for
  * 3-d labels and the autograd backward: A-ch/attacks/fast_gradient_method.py:131-142, V-ch/...:115-126.
  * Algorithmic bytes: 8*V per row (read the logits once from HBM, write the gradient once). */
 int vqa_ce_max_label_sets(void);
+int vqa_ce_scratch_floats(void);
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
-                long ignore_index, float* inv_count, float* grad, float* row_loss, float gscale,
-                vqa_stream_t stream);
+                long ignore_index, float* scratch, float* grad, float* row_loss, float gscale, float* loss_out,
+                int accumulate, int* flag, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- text side
  * dst[b, k, :] = src[b, idx[k], :]  for src (B, L, D), idx int64[K] with 0 <= idx[k] < L.

@@ -12,7 +12,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vqattack_amd import ops  # noqa: E402
+from vqattack_amd import _hip, ops  # noqa: E402
 
 PEAK = 8000.0
 
@@ -39,7 +39,10 @@ def report(name, nbytes, ms, note=""):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--sections", default="linf,copy,norm,cos,ce,text",
+                    help="comma list of: linf, copy, norm, cos, ce, text")
     args = ap.parse_args()
+    sections = set(args.sections.split(","))
     b = args.batch
     shape = (b, 3, 384, 384)
     n = b * 3 * 384 * 384
@@ -49,6 +52,37 @@ def main():
     x = torch.clamp(x0 + eta, -1, 1)
     g = torch.randn(shape, device="cuda", generator=gen)
     out = torch.empty_like(x)
+    if "copy" in sections:
+        copy_probes(x, x0, g, out, n)
+    if "linf" in sections:
+        linf_section(x, x0, g, eta, out, n)
+    if "norm" in sections:
+        norm_section(x, x0, g, out, n)
+    del eta, out
+    if "cos" in sections:
+        cos_section(b)
+    if "ce" in sections:
+        ce_section(b)
+    if "text" in sections:
+        text_section(b)
+
+
+def copy_probes(x, x0, g, out, n):
+    """What plain copies reach at the SAME footprint, in the same harness (events around back-to-back launches): the
+    yardstick for 'the platform's streaming rate' next to the 8 TB/s spec."""
+    report("probe: torch copy_ (ATen / hipMemcpyAsync D2D), 1r:1w", 8 * n, timeit(lambda: out.copy_(x)))
+    report("probe: stream4 skeleton 1r:1w (vqa_clip_eta_linf, eps=inf -> copy)", 8 * n,
+           timeit(lambda: ops.clip_eta_linf(x, float("inf"))), "allocates its output per call")
+    report("probe: stream4 skeleton 2r:1w (vqa_linf_project)", 12 * n,
+           timeit(lambda: ops.linf_project(x, x0, 0.125, -1, 1, out=out)))
+    big = torch.cat([x.reshape(-1), x0.reshape(-1)])          # 2 images' worth: same bytes per launch as the 3r:1w step
+    dst = torch.empty_like(big)
+    report("probe: torch copy_ at the step kernel's footprint (16 B/el of the image batch)", 16 * n,
+           timeit(lambda: dst.copy_(big)))
+    del big, dst
+
+
+def linf_section(x, x0, g, eta, out, n):
     report("vqa_linf_step", 16 * n, timeit(lambda: ops.linf_step(x, g, x0, 0.01, 0.125, -1, 1, out=out)))
     def eager_chain():
         # the reference's op chain between two model calls, as PyTorch-ROCm runs it (SURVEY.md section 2.3, rows 1-13
@@ -64,45 +98,105 @@ def main():
     report("vqa_linf_init (eta)", 12 * n, timeit(lambda: ops.linf_init(x0, eta, 0.125, -1, 1, out=out)))
     report("vqa_linf_init (zero)", 8 * n, timeit(lambda: ops.linf_init(x0, None, 0.125, -1, 1, out=out)))
     report("vqa_linf_project", 12 * n, timeit(lambda: ops.linf_project(x, x0, 0.125, -1, 1, out=out)))
+
+
+def norm_section(x, x0, g, out, n):
     report("vqa_sumsq_per_sample", 4 * n, timeit(lambda: ops.sumsq_per_sample(g)), "two-stage deterministic")
     report("vqa_sumsq_per_sample (diff)", 8 * n, timeit(lambda: ops.sumsq_per_sample(x, sub=x0)))
     report("l2_fgm (sumsq + update)", 4 * n + 12 * n, timeit(lambda: ops.l2_fgm(x, g, 0.5, -1, 1, out=out)),
            "gradient read twice (norm, then update)")
     report("l2_project (sumsq + update)", 8 * n + 12 * n, timeit(lambda: ops.l2_project(x, x0, 2.0, -1, 1, out=out)))
     report("l1_fgm (absmax/ties + update)", 4 * n + 12 * n, timeit(lambda: ops.l1_fgm(x, g, 0.5, -1, 1, out=out)))
-    del eta, out
-    # cosine loss at the VLMO-base per-layer shape
-    a = torch.randn(b, 617, 768, device="cuda")
-    t = torch.randn(b, 617, 768, device="cuda")
+
+
+def cos_section(b):
+    # cosine loss at the VLMO-base per-layer shape; the gradient buffer comes from a Workspace (as in the attack loop)
+    ws = ops.Workspace()
     slot = torch.zeros(1, device="cuda")
     rows = b * 617
+    a = torch.randn(b, 617, 768, device="cuda")
+    t = torch.randn(b, 617, 768, device="cuda")
     report("vqa_neg_cos_rows (loss+grad, D=768)", 12 * rows * 768,
-           timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False)), "incl. sum_partials + grad alloc")
+           timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False, ws=ws)), "loss folded in the launch")
     report("vqa_neg_cos_rows (loss only, D=768)", 8 * rows * 768,
            timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False, want_grad=False)))
+    report("vqa_neg_cos_rows (loss+grad, D=768), partials only (no in-kernel fold)", 12 * rows * 768,
+           timeit(lambda: ops.neg_cos_rows(a, t, None, accumulate=False, ws=ws)), "A/B: cost of the arrival counters")
+    for per_cu, inflight in ((0, 1), (8, 2), (8, 1), (4, 2), (0, 2)):     # last = defaults
+        assert _hip.lib().vqa_set_option(6, per_cu) == 0 and _hip.lib().vqa_set_option(7, inflight) == 0
+        report("vqa_neg_cos_rows (loss+grad, D=768) [grid {}, {} row(s) in flight]".format(
+            "resident" if per_cu == 0 else "{}/CU".format(per_cu), inflight), 12 * rows * 768,
+            timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False, ws=ws)), "A/B knob sweep")
+    w = torch.ones(b, 617, dtype=torch.uint8, device="cuda")
+    w[:, 0] = 2
+    w[:, 10:40] = 0                        # 10 real text tokens of 40, as in the bench workload
+    live = int((w != 0).sum())
+    report("vqa_neg_cos_rows (loss+grad, D=768, row weights: 30 of 617 rows padded)", 12 * live * 768,
+           timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws)),
+           "bytes of live rows only")
     del a, t
-    a = torch.randn(b, 617, 1024, device="cuda")
-    t = torch.randn(b, 617, 1024, device="cuda")
+    n_layers = 13 if b <= 64 else 4        # 13 maps at batch 64 = 4.5 GB per launch x 3 buffers
+    al = [torch.randn(b, 617, 768, device="cuda") for _ in range(n_layers)]
+    tl = [torch.randn(b, 617, 768, device="cuda") for _ in range(n_layers)]
+    report("vqa_neg_cos_rows_multi ({} layers, loss+grad, D=768)".format(n_layers), 12 * rows * 768 * n_layers,
+           timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10),
+           "the attack loop's launch: every per-layer map of a modality at once")
+    report("vqa_neg_cos_rows_multi ({} layers, row weights)".format(n_layers), 12 * live * 768 * n_layers,
+           timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
+                  reps=10))
+    for nt in (0, 5, 6, 7, 4):
+        assert _hip.lib().vqa_set_option(8, nt) == 0
+        report("vqa_neg_cos_rows_multi ({} layers, D=768) [nt mask {}: a loads {}, grad stores {}, b loads {}]".format(
+            n_layers, nt, "nt" if nt & 1 else "plain", "nt" if nt & 2 else "plain", "nt" if nt & 4 else "plain"),
+            12 * rows * 768 * n_layers,
+            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B knob sweep")
+    for per_cu, inflight in ((0, 1), (8, 2), (8, 1), (0, 2)):
+        assert _hip.lib().vqa_set_option(6, per_cu) == 0 and _hip.lib().vqa_set_option(7, inflight) == 0
+        report("vqa_neg_cos_rows_multi ({} layers, D=768) [grid {}, {} row(s) in flight]".format(
+            n_layers, "resident" if per_cu == 0 else "{}/CU".format(per_cu), inflight), 12 * rows * 768 * n_layers,
+            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B knob sweep")
+    del al, tl, ws
+    ws = ops.Workspace()
+    n_layers = 25 if b <= 64 else 4
+    al = [torch.randn(b, 617, 1024, device="cuda") for _ in range(n_layers)]
+    tl = [torch.randn(b, 617, 1024, device="cuda") for _ in range(n_layers)]
     report("vqa_neg_cos_rows (loss+grad, D=1024)", 12 * rows * 1024,
-           timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False)))
-    del a, t
+           timeit(lambda: ops.neg_cos_rows(al[0], tl[0], slot, accumulate=False, ws=ws)))
+    report("vqa_neg_cos_rows_multi ({} layers, loss+grad, D=1024)".format(n_layers), 12 * rows * 1024 * n_layers,
+           timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=6),
+           "VLMO-large: 25 maps in one launch")
+
+
+def ce_section(b):
     # MLM cross entropy (B*40 rows of 30522)
+    import torch.nn.functional as F
+    slot = torch.zeros(1, device="cuda")
     rows = b * 40
     logits = torch.randn(rows, 30522, device="cuda")
     labels = torch.randint(0, 30522, (1, rows), device="cuda")
-    report("vqa_ce_rows (loss+grad, K=1)", 8 * rows * 30522,
-           timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False)), "row re-read from L2 not counted")
     labels3 = torch.randint(0, 30522, (3, rows), device="cuda")
+    ws = ops.Workspace()
+    for per_cu, threads in ((2, 256), (3, 256), (2, 512)):
+        assert _hip.lib().vqa_set_option(5, per_cu) == 0 and _hip.lib().vqa_set_option(4, threads) == 0
+        tag = "{} workgroups/CU, {} threads".format(per_cu, threads)
+        report("vqa_ce_rows (loss+grad, K=1) [{}]".format(tag), 8 * rows * 30522,
+               timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, ws=ws)))
+        report("vqa_ce_rows (loss+grad, K=1) [{}], row losses only (no in-kernel fold)".format(tag), 8 * rows * 30522,
+               timeit(lambda: ops.mlm_cross_entropy(logits, labels, None, accumulate=False, ws=ws)), "A/B")
+    assert _hip.lib().vqa_set_option(5, 2) == 0 and _hip.lib().vqa_set_option(4, 256) == 0      # defaults
     report("vqa_ce_rows (loss+grad, K=3)", 8 * rows * 30522,
-           timeit(lambda: ops.mlm_cross_entropy(logits, labels3, slot, accumulate=False)))
-    import torch.nn.functional as F
+           timeit(lambda: ops.mlm_cross_entropy(logits, labels3, slot, accumulate=False, ws=ws)))
+    report("vqa_ce_rows (loss only, K=1)", 4 * rows * 30522,
+           timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, want_grad=False, ws=ws)))
 
     def torch_ce():
         lg = logits.detach().requires_grad_(True)
         F.cross_entropy(lg, labels[0]).backward()
     report("torch F.cross_entropy fwd+bwd (K=1), same bytes basis", 8 * rows * 30522, timeit(torch_ce),
            "PyTorch-ROCm eager reference for the op the kernel replaces")
-    del logits
+
+
+def text_section(b):
     # text gradient gather + candidate scoring
     tg = torch.randn(b, 40, 768, device="cuda")
     idx = list(range(40))

@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvqattack_hip.so")
 
 VQA_CLIP = 1
 VQA_CHECK_RANGE = 2
+VQA_FLAG_RANGE = 1        # bits of a flag word
+VQA_FLAG_BAD_LABEL = 2
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -44,12 +47,13 @@ SIGNATURES = {
     "vqa_l1_fgm": (_i, [_p, _p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p, _p]),
     "vqa_scale_per_sample": (_i, [_p, _p, _p, _p, _i, _sz, _f, _i, _p]),
     "vqa_neg_cos_partials": (_i, []),
-    "vqa_neg_cos_rows": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p]),
+    "vqa_neg_cos_rows": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p, _i, _p]),
     "vqa_neg_cos_max_layers": (_i, []),
-    "vqa_neg_cos_rows_multi": (_i, [_p, _p, _p, _i, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p]),
+    "vqa_neg_cos_rows_multi": (_i, [_p, _p, _p, _i, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p, _i, _p]),
     "vqa_sum_partials": (_i, [_p, _i, _p, _i, _f, _p]),
     "vqa_ce_max_label_sets": (_i, []),
-    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _p, _p, _p, _f, _p]),
+    "vqa_ce_scratch_floats": (_i, []),
+    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _p, _p, _p, _f, _p, _i, _p, _p]),
     "vqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_embed_tokens": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
@@ -76,6 +80,9 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.vqa_abi_version() != ABI_VERSION:
+        raise HipExtensionError("{} implements C ABI version {}, this package binds version {}: rebuild it with "
+                                "`python -m vqattack_amd.build --force`".format(path, lib.vqa_abi_version(), ABI_VERSION))
     # development overrides of the tuning knobs: VQA_OPTIONS="1=3,0=8" -> vqa_set_option(1, 3); vqa_set_option(0, 8)
     for item in filter(None, os.environ.get("VQA_OPTIONS", "").split(",")):
         opt, val = item.split("=")

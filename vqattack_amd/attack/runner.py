@@ -229,6 +229,7 @@ class BatchedVQAttack:
             eta = torch.empty_like(images).uniform_(-c.eps, c.eps)
         cur = ops.linf_init(images.contiguous(), eta, c.eps, c.clip_min, c.clip_max, flag=flag)
         losses = torch.zeros(max(total), dtype=torch.float32, device=dev)
+        ws = ops.Workspace()
         res = BatchResult(adv_images=cur, adv_text_ids=adv_ids)
         n_act_prev = None
         for t in range(max(total)):
@@ -241,7 +242,7 @@ class BatchedVQAttack:
             leaf_img = cur[:n_act].detach().requires_grad_(True)
             leaf_txt = adv_emb[:n_act].detach().requires_grad_(True)
             attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1, self.flavor,
-                                   False, attacks._LossSlot(losses, t), vl=True)
+                                   False, attacks._LossSlot(losses, t), vl=True, ws=ws)
             ops.linf_step(cur[:n_act], leaf_img.grad, images[:n_act], c.eps_iter, c.eps, c.clip_min, c.clip_max,
                           out=cur[:n_act])                                # in place: finished samples stay untouched
             firing = [s for s in range(n_act) if t in probes[s]]

@@ -115,7 +115,7 @@ def _feature_pairs(out, y, flavor, vl):
     return [(out[1], y[1]), (out[2], y[2])]
 
 
-def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=None):
+def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=None, ws=None):
     """Fused loss + gradient: one HIP pass per pair, then autograd through the model only.
 
     loss = sign * extra_scale * sum_pairs sum_rows -cos (+ whatever ``extra()`` adds).  ``extra`` is an optional
@@ -125,7 +125,7 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=Non
     tensors, grads = [], []
     gscale = sign * extra_scale
     first = True
-    for (o_pair, t_pair) in pairs:
+    for pair_index, (o_pair, t_pair) in enumerate(pairs):
         trips = layer_pairs(o_pair, t_pair)                 # per-layer (out, target, row weight)
         outs, tgts = [], []
         for (o, t, _) in trips:
@@ -143,7 +143,8 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=Non
                 continue
             ga = ops.neg_cos_rows_multi([outs[i].detach() for i in idx], [tgts[i] for i in idx], slot.word,
                                         accumulate=not first, gscale=gscale, want_grad=needs_grad, row_weight=w,
-                                        weight_period=period)      # ONE launch for all layers of this modality
+                                        weight_period=period,      # ONE launch for all layers of this modality
+                                        ws=None if ws is None else ops._Sub(ws, pair_index))
             first = False
             if needs_grad:
                 tensors += [outs[i] for i in idx]
@@ -168,28 +169,31 @@ def _label_sets(labels):
     raise ValueError("MLM labels must be 2-d or 3-d")
 
 
-def _ce_backward(logits, label_sets, slot, leaves, sign, scale=1.0, accumulate=False):
+def _ce_backward(logits, label_sets, slot, leaves, sign, scale=1.0, accumulate=False, flag=None, ws=None):
     """Fused cross entropy: loss into ``slot``; returns ``(tensors, grads)`` for the autograd sweep (one HIP launch)."""
     if logits.shape[-1] != MLM_VOCAB:
         logits = logits.reshape(-1, MLM_VOCAB)          # the reference's .view(-1, 30522)
     l32 = logits if logits.dtype == torch.float32 else logits.to(torch.float32)
     needs_grad = l32.requires_grad
     g = ops.mlm_cross_entropy(l32.detach(), label_sets, slot.word, accumulate=accumulate, gscale=sign * scale,
-                              want_grad=needs_grad)
+                              want_grad=needs_grad, flag=flag, ws=ws)
     return ([l32], [g]) if needs_grad else ([], [])
 
 
-def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bkp=None, bkp_y=None, vl=False):
-    """Run the white box, evaluate the selected loss into ``slot`` and leave d loss/d leaf in ``leaf.grad``."""
+def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bkp=None, bkp_y=None, vl=False,
+                   ws=None, flag=None):
+    """Run the white box, evaluate the selected loss into ``slot`` and leave d loss/d leaf in ``leaf.grad``.
+    ``ws`` (``ops.Workspace``): gradient / scratch buffers reused across the iterations of one attack call;
+    ``flag``: the attack's int32 device word (bad MLM labels are reported there, see ``ops.mlm_cross_entropy``)."""
     sign = -1.0 if targeted else 1.0
     with torch.enable_grad():
         out = model_fn(model_in)
         if vl:
             pairs = _feature_pairs(out, y, flavor, vl=True)     # truncation happens before the `ls` switch
             if ls == 1:
-                _feature_loss_backward(pairs, slot, leaves, sign)
+                _feature_loss_backward(pairs, slot, leaves, sign, ws=ws)
             elif ls == 0:
-                t, g = _ce_backward(out[0], y[0].reshape(1, -1), slot, leaves, sign)
+                t, g = _ce_backward(out[0], y[0].reshape(1, -1), slot, leaves, sign, flag=flag, ws=ws)
                 torch.autograd.backward(t, g, inputs=leaves)
             else:
                 raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
@@ -207,9 +211,9 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             if bad:
                 ls, out, y = 1, bkp(model_in), bkp_y
         if ls == 1:
-            _feature_loss_backward(_feature_pairs(out, y, flavor, vl=False), slot, leaves, sign)
+            _feature_loss_backward(_feature_pairs(out, y, flavor, vl=False), slot, leaves, sign, ws=ws)
         elif ls == 0:
-            t, g = _ce_backward(out[0], _label_sets(y[0]), slot, leaves, sign)
+            t, g = _ce_backward(out[0], _label_sets(y[0]), slot, leaves, sign, flag=flag, ws=ws)
             if not t:
                 raise RuntimeError("model_fn's logits do not depend on the attacked input")
             torch.autograd.backward(t, g, inputs=leaves)
@@ -219,9 +223,9 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
             scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
             pairs = [(out[2], y[2])] if out[1] is None else [(out[1], y[1]), (out[2], y[2])]
-            _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=scale,
+            _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=scale, ws=ws,
                                    extra=lambda: _ce_backward(out[0], sets, slot, leaves, sign, scale=0.1,
-                                                              accumulate=True))
+                                                              accumulate=True, flag=flag, ws=ws))
         else:
             raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
 
@@ -262,7 +266,8 @@ def fast_gradient_method(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=
     flag = ops.new_flag(xin.device) if (sanity_checks and (clip_min is not None or clip_max is not None)) else None
     leaf = xin.detach().requires_grad_(True)           # shares storage with x: nothing is written in place
     loss_buf = torch.zeros(1, dtype=torch.float32, device=xin.device)
-    _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, 0), bkp=bkp, bkp_y=bkp_y)
+    _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, 0), bkp=bkp, bkp_y=bkp_y,
+                   flag=flag)
     _two_sided(clip_min, clip_max)
     adv = _fgm_update(xin, _grad_of(leaf), eps, norm, clip_min, clip_max, flag=flag)
     if sanity_checks and flag is not None:
@@ -387,6 +392,8 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     dual = ls != 1
     loss_buf = torch.zeros(max(nb_iter, 1) * (2 if dual else 1), dtype=torch.float32, device=xin.device)
     n_loss = 0
+    ws = ops.Workspace()       # loss-gradient / CE scratch buffers live for the whole call, not per iteration
+    bad_flag = flag if flag is not None else (ops.new_flag(xin.device) if (dual and sanity_checks) else None)
     if graph and nb_iter > 0:
         if dual or norm != np.inf:
             raise ValueError("graph=True supports the feature-loss (ls == 1) L-inf loop only")
@@ -397,7 +404,8 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     for _ in range(nb_iter):
         if not dual:
             leaf = adv.detach().requires_grad_(True)
-            _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, n_loss))
+            _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, n_loss), ws=ws,
+                           flag=bad_flag)
             n_loss += 1
             _two_sided(clip_min, clip_max)
             adv = _fgm_then_project(adv, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])
@@ -407,18 +415,20 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
             else:
                 y_feat, y_mlm, extra = y, y, {}
             leaf = adv.detach().requires_grad_(True)
-            _loss_and_grad(model_fn[0], [leaf], leaf, y_feat, 1, flavor, targeted, _LossSlot(loss_buf, n_loss))
+            _loss_and_grad(model_fn[0], [leaf], leaf, y_feat, 1, flavor, targeted, _LossSlot(loss_buf, n_loss), ws=ws,
+                           flag=bad_flag)
             n_loss += 1
             _two_sided(clip_min, clip_max)
             mid = _fgm_update(adv, _grad_of(leaf), eps_iter, norm, clip_min, clip_max, out=buf[1 - cur])
             leaf = mid.detach().requires_grad_(True)
-            _loss_and_grad(model_fn[1], [leaf], leaf, y_mlm, 0, flavor, targeted, _LossSlot(loss_buf, n_loss), **extra)
+            _loss_and_grad(model_fn[1], [leaf], leaf, y_mlm, 0, flavor, targeted, _LossSlot(loss_buf, n_loss), ws=ws,
+                           flag=bad_flag, **extra)
             n_loss += 1
             adv = _fgm_then_project(mid, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[cur])
             cur = 1 - cur            # result sits in buf[cur] again after the flip below
         cur = 1 - cur
         del leaf
-    _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)
+    _finish(bad_flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)
     loss_list = loss_buf[:n_loss].tolist()     # single device->host transfer for the whole loop
     return adv, loss_list
 
@@ -446,11 +456,12 @@ def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, cli
         raise ValueError("projected_gradient_descent_vl supports ls == 1 only")
     text_grad = None
     loss_buf = torch.zeros(max(nb_iter, 1), dtype=torch.float32, device=img.device)
+    ws = ops.Workspace()
     for it in range(nb_iter):
         leaf_img = adv.detach().requires_grad_(True)
         leaf_txt = emb.detach().requires_grad_(True)
         _loss_and_grad(model_fn, [leaf_img, leaf_txt], [leaf_img, leaf_txt], y, ls, flavor, targeted,
-                       _LossSlot(loss_buf, it), vl=True)
+                       _LossSlot(loss_buf, it), vl=True, ws=ws, flag=flag)
         text_grad = ops.gather_rows(_grad_of(leaf_txt), attack_mask)
         _two_sided(clip_min, clip_max)
         adv = _fgm_then_project(adv, _grad_of(leaf_img), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])

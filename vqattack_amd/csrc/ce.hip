@@ -1,23 +1,40 @@
 // Masked-LM cross entropy over the 30522-word vocabulary: loss AND d loss / d logits in one launch (gfx950 / MI355X).
 //
-// One 256-thread workgroup per logits row (V = 30522 floats = 119 KB): sweep 1 streams the row from HBM with 8-byte
-// loads and keeps a per-lane online (max, sum-exp); the 4 waves combine through DPP shuffles + LDS; sweep 2 re-reads
-// the row -- L2-resident, the row is far below the 4 MB XCD L2 -- and writes the gradient
+// Register-resident kernel (ce_rows_reg_kernel, V <= 32760): one 256-thread workgroup per logits row keeps the whole
+// row in registers (32 float4 per lane), so the logits cross HBM exactly once and nothing is re-read, not even from
+// L2; max and sum-exp are two-step block reductions (DPP within a wave, LDS across the 4 waves), exp() is evaluated
+// once per element, and the gradient
 //     g_j = gscale * ( softmax_j * sum_k w_k  -  sum_k w_k [j == label_k] ),   w_k = 1/n_valid_k or 0 when ignored
-// for ALL K label sets at once (the reference sums K separate F.cross_entropy calls over the same logits:
-// A-ch/attacks/fast_gradient_method.py:136-139).  Algorithmic bytes: 4*V read + 4*V written per row (8*V), against
-// ~6 full passes per label set for log_softmax + nll_loss + their autograd backward.
+// is written for ALL K label sets at once (the reference sums K separate F.cross_entropy calls over the same logits:
+// A-ch/attacks/fast_gradient_method.py:136-139).  The workgroup that finishes last folds the per-row losses in row
+// order into the scalar loss (relaxed two-level arrival counters, common.hpp): no second launch.
+// exp is the hardware v_exp_f32 path (__expf, ~2 ulp); the tests state 1e-4 relative against torch.
+// A label that is neither ignore_index nor in [0, V) poisons the loss with NaN and ORs VQA_FLAG_BAD_LABEL into *flag
+// (torch device-asserts on such a label; it is never silently dropped).
+// Algorithmic bytes: 4*V read + 4*V written per row (8*V), against ~6 full passes per label set for log_softmax +
+// nll_loss + their autograd backward.
 #include "common.hpp"
+
+extern "C" int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
+                                vqa_stream_t stream);   // loss.hip
 
 namespace vqa {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWaves = kBlock / kWave;
 
-// inv_count[k] = 1 / #{r : labels[k][r] != ignore}   (F.cross_entropy's mean over non-ignored targets)
+constexpr int kCeMaxK = 8;
+constexpr int kCeCounterSlot = kCeMaxK;       // scratch layout: K reciprocal counts, then the fold's arrival counters
+constexpr int kCeScratchFloats = kCeMaxK + kArriveWords;
+
+// inv_count[k] = 1 / #{r : labels[k][r] != ignore}   (F.cross_entropy's mean over non-ignored targets);
+// block 0 also zeroes the arrival counter of the in-kernel loss fold.
 __global__ __launch_bounds__(kBlock) void ce_count_kernel(const int64_t* __restrict__ labels, long rows,
                                                           long ignore_index, float* __restrict__ inv_count) {
   __shared__ float lds[kWaves];
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kArriveWords; i += kBlock) reinterpret_cast<unsigned*>(inv_count)[kCeCounterSlot + i] = 0u;
   const int64_t* lab = labels + static_cast<long>(blockIdx.x) * rows;
   float c = 0.0f;
   for (long r = threadIdx.x; r < rows; r += kBlock) c += (lab[r] != ignore_index) ? 1.0f : 0.0f;
@@ -31,18 +48,92 @@ __global__ __launch_bounds__(kBlock) void ce_count_kernel(const int64_t* __restr
   }
 }
 
+// Per-row label bookkeeping shared by the kernels: weights of the K label sets, their sum, the row's loss.
+template <int MAXK>
+struct RowLabels {
+  long lab[MAXK];
+  float wk[MAXK];
+  float wsum, loss;
+  bool bad;
+};
+
+template <int MAXK>
+__device__ __forceinline__ RowLabels<MAXK> read_labels(const int64_t* __restrict__ labels, int K, long rows, long r,
+                                                       int V, long ignore_index,
+                                                       const float* __restrict__ inv_count,
+                                                       const float* __restrict__ x, float lse) {
+  RowLabels<MAXK> L;
+  L.wsum = 0.0f;
+  L.loss = 0.0f;
+  L.bad = false;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    L.lab[k] = -1;
+    L.wk[k] = 0.0f;
+    if (k < K) {
+      const long t = labels[static_cast<long>(k) * rows + r];
+      if (t != ignore_index) {
+        if (t >= 0 && t < V) {
+          L.lab[k] = t;
+          L.wk[k] = inv_count[k];
+          L.wsum += L.wk[k];
+          L.loss += L.wk[k] * (lse - x[t]);
+        } else {
+          L.bad = true;
+        }
+      }
+    }
+  }
+  if (L.bad) L.loss = __builtin_nanf("");
+  return L;
+}
+
+struct CeFold {          // in-kernel fold of row_loss into the scalar loss (loss_out == NULL: row losses only)
+  unsigned* counter;
+  float* loss_out;
+  int accumulate;
+  float scale;
+};
+
+// Called by every thread of every workgroup at the end of a kernel whose thread 0 wrote row_loss with agent-scope
+// stores: the workgroup that arrives last sums row_loss[0 .. rows) in row order.
+template <int THREADS>
+__device__ __forceinline__ void fold_row_losses(const CeFold& fold, const float* row_loss, long rows) {
+  if (!fold.loss_out) return;
+  __shared__ int lds_last;
+  __shared__ float lds_f[THREADS / kWave];
+  if (threadIdx.x == 0) lds_last = arrive_is_last(fold.counter) ? 1 : 0;   // row losses were stored write-through
+  __syncthreads();
+  if (!lds_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  float acc = 0.0f;
+  for (long i = threadIdx.x; i < rows; i += THREADS)
+    acc += __hip_atomic_load(row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) lds_f[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = lds_f[0];
+#pragma unroll
+    for (int w = 1; w < THREADS / kWave; ++w) s += lds_f[w];
+    s *= fold.scale;
+    fold.loss_out[0] = fold.accumulate ? fold.loss_out[0] + s : s;
+  }
+}
+
 __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
   const float mm = fmaxf(m, m2);
   s = s * expf(m - mm) + s2 * expf(m2 - mm);
   m = mm;
 }
 
+// ---- streaming fallback (any V, strided / unaligned rows): two sweeps, the second re-reads the row from L2 ----
 template <bool GRAD, int MAXK>
 __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict__ logits, long row_stride,
                                                          const int64_t* __restrict__ labels, int K, long rows, int V,
                                                          long ignore_index, const float* __restrict__ inv_count,
                                                          float* __restrict__ grad, float* __restrict__ row_loss,
-                                                         float gscale) {
+                                                         float gscale, int* __restrict__ flag) {
   __shared__ float lds_m[kWaves], lds_s[kWaves];
   const long r = blockIdx.x;
   const float* x = logits + r * row_stride;
@@ -79,25 +170,11 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
   for (int w = 1; w < kWaves; ++w)
     if (lds_m[w] != -INFINITY || m != -INFINITY) online_merge(m, s, lds_m[w], lds_s[w]);
   const float lse = m + logf(s);
-  // ---- per-row label bookkeeping (K <= MAXK label sets)
-  long lab[MAXK];
-  float wk[MAXK];
-  float wsum = 0.0f, loss = 0.0f;
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    lab[k] = -1;
-    wk[k] = 0.0f;
-    if (k < K) {
-      const long t = labels[static_cast<long>(k) * rows + r];
-      if (t != ignore_index && t >= 0 && t < V) {
-        lab[k] = t;
-        wk[k] = inv_count[k];
-        wsum += wk[k];
-        loss += wk[k] * (lse - x[t]);
-      }
-    }
+  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, inv_count, x, lse);
+  if (threadIdx.x == 0) {
+    row_loss[r] = L.loss;
+    if (L.bad && flag) atomicOr(flag, VQA_FLAG_BAD_LABEL);
   }
-  if (threadIdx.x == 0) row_loss[r] = loss;
   if (!GRAD) return;
   // ---- sweep 2: gradient (row re-read from L2)
   float* g = grad + r * static_cast<long>(V);
@@ -109,63 +186,74 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
     f32x2 o;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      float val = wsum * (expf(v[e] - m) * inv_s);
+      float val = L.wsum * (expf(v[e] - m) * inv_s);
 #pragma unroll
-      for (int k = 0; k < MAXK; ++k) val -= (lab[k] == 2 * j + e) ? wk[k] : 0.0f;
+      for (int k = 0; k < MAXK; ++k) val -= (L.lab[k] == 2 * j + e) ? L.wk[k] : 0.0f;
       o[e] = gscale * val;
     }
     __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(g) + j);
   }
   for (int j = 2 * g2 + threadIdx.x; j < V; j += kBlock) {
-    float val = wsum * (expf(x[j] - m) * inv_s);
+    float val = L.wsum * (expf(x[j] - m) * inv_s);
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) val -= (lab[k] == j) ? wk[k] : 0.0f;
+    for (int k = 0; k < MAXK; ++k) val -= (L.lab[k] == j) ? L.wk[k] : 0.0f;
     g[j] = gscale * val;
   }
 }
 
-// Register-resident variant for V <= 32768 (the MLM vocabulary is 30522): the whole row is held as 32 float4 per
-// lane, so the logits cross HBM exactly once and nothing is re-read, not even from L2; max and sum-exp are plain
-// two-step block reductions (no serial online-rescale chain), exp() is evaluated once per element.
+// ---- register-resident persistent kernel ----------------------------------------------------------------------
 // Rows of 30522 floats start 8 bytes off a 16-byte boundary every other row, so a row is split into a <= 3 element
 // head, a 16-byte aligned body of float4 and a <= 3 element tail (8-byte accesses run at 0.54-0.70x the 16-byte rate
-// on this chip, MI355X_MICROARCH.md).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// on this chip, MI355X_MICROARCH.md).  Lane t < head owns x[t]; lane 8 + t owns tail element t.
 constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
-static int g_ce_threads = 256;        // vqa_set_option(4, 256 | 512 | 1024); 256 measured fastest at 2 WG/CU
+static int g_ce_threads = 256;        // vqa_set_option(4, 256 | 512 | 1024)
+static int g_ce_variant = 2;          // vqa_set_option(5, n): n = workgroups resident per CU (2 or 3; 3 only at 256 threads)
 
-// launch bounds: two workgroups per CU whatever THREADS is (2 * THREADS / 256 waves per SIMD), so that one row's
-// reduce/exp phase overlaps the other's HBM phase; that caps the kernel at 64 VGPRs for THREADS = 1024
-constexpr int ce_blocks_per_cu(int) { return 2; }   // 3 per CU forces spills at 256 threads: 181 us vs 130 us
+struct RowGeom {
+  const f32x4* x4;      // aligned body
+  const float* x;       // row start
+  int head, nquad, tail0;
+};
 
-template <bool GRAD, int MAXK, int THREADS>
-__global__ __launch_bounds__(THREADS, ce_blocks_per_cu(THREADS) * THREADS / 256) void ce_rows_reg_kernel(const float* __restrict__ logits, long row_stride,
-                                                             const int64_t* __restrict__ labels, int K, long rows,
-                                                             int V, long ignore_index,
-                                                             const float* __restrict__ inv_count,
-                                                             float* __restrict__ grad, float* __restrict__ row_loss,
-                                                             float gscale) {
+__device__ __forceinline__ RowGeom row_geom(const float* logits, long r, int V) {
+  RowGeom g;
+  // logits base is 16-byte aligned and rows are dense (host check): the alignment phase follows from the offset
+  g.head = static_cast<int>((4 - ((r * V) & 3)) & 3);
+  g.nquad = (V - g.head) / 4;
+  g.tail0 = g.head + 4 * g.nquad;
+  g.x = logits + r * V;
+  g.x4 = reinterpret_cast<const f32x4*>(g.x + g.head);
+  return g;
+}
+
+__device__ __forceinline__ int edge_index(const RowGeom& g, int V) {
+  if (static_cast<int>(threadIdx.x) < g.head) return threadIdx.x;
+  if (threadIdx.x >= 8 && static_cast<int>(threadIdx.x) < 8 + (V - g.tail0)) return g.tail0 + (threadIdx.x - 8);
+  return -1;
+}
+
+// One workgroup per row; WGPC workgroups are resident per CU (launch bounds), so one row's reduce / exp phase overlaps
+// the HBM phases of the others.  (A persistent variant that streamed row r's gradient out while loading row r + grid
+// into the same registers measured 5-8 % slower: the loads then issue behind the store's VALU work instead of in one
+// burst at workgroup start -- profiles/r02/kernel_roofline_ab_b64.jsonl.)
+template <bool GRAD, int MAXK, int THREADS, int WGPC>
+__global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels, int K, long rows, int V, long ignore_index,
+    const float* __restrict__ inv_count, float* __restrict__ grad, float* __restrict__ row_loss, float gscale,
+    int* __restrict__ flag, CeFold fold) {
   constexpr int kQuads = kRegFloats / 4 / THREADS;
   constexpr int kWavesT = THREADS / kWave;
   __shared__ float lds[kWavesT];
   const long r = blockIdx.x;
-  const float* x = logits + r * row_stride;
-  // logits base is 16-byte aligned (host check): alignment of the row start follows from its element offset
-  const int head = static_cast<int>((4 - ((r * row_stride) & 3)) & 3);
-  const int nquad = (V - head) / 4;
-  const int tail0 = head + 4 * nquad;              // first tail element
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + head);
+  const RowGeom cur = row_geom(logits, r, V);
   f32x4 v[kQuads];
 #pragma unroll
   for (int i = 0; i < kQuads; ++i) {
     const int j = i * THREADS + threadIdx.x;
-    v[i] = (j < nquad) ? x4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    v[i] = (j < cur.nquad) ? cur.x4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   }
-  // the <= 6 leftover elements: lane t < head owns x[t]; lane 8 + t owns x[tail0 + t]
-  int edge = -1;
-  if (threadIdx.x < head) edge = threadIdx.x;
-  else if (threadIdx.x >= 8 && threadIdx.x < 8 + (V - tail0)) edge = tail0 + (threadIdx.x - 8);
-  float ve = (edge >= 0) ? x[edge] : -INFINITY;
+  const int edge = edge_index(cur, V);
+  float ve = (edge >= 0) ? cur.x[edge] : -INFINITY;
   float m = ve;
 #pragma unroll
   for (int i = 0; i < kQuads; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
@@ -193,49 +281,66 @@ __global__ __launch_bounds__(THREADS, ce_blocks_per_cu(THREADS) * THREADS / 256)
 #pragma unroll
   for (int w = 1; w < kWavesT; ++w) s += lds[w];
   const float lse = m + logf(s);
-  long lab[MAXK];
-  float wk[MAXK];
-  float wsum = 0.0f, loss = 0.0f;
+  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, inv_count, cur.x, lse);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(row_loss + r, L.loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (L.bad && flag) atomicOr(flag, VQA_FLAG_BAD_LABEL);
+  }
+  if (GRAD) {
+    float* g = grad + r * static_cast<long>(V);
+    const float c = L.wsum / s;
+    if (edge >= 0) {
+      float val = c * ve;
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    lab[k] = -1;
-    wk[k] = 0.0f;
-    if (k < K) {
-      const long t = labels[static_cast<long>(k) * rows + r];
-      if (t != ignore_index && t >= 0 && t < V) {
-        lab[k] = t;
-        wk[k] = inv_count[k];
-        wsum += wk[k];
-        loss += wk[k] * (lse - x[t]);
+      for (int k = 0; k < MAXK; ++k) val -= (L.lab[k] == edge) ? L.wk[k] : 0.0f;
+      g[edge] = gscale * val;
+    }
+    f32x4* g4 = reinterpret_cast<f32x4*>(g + cur.head);
+#pragma unroll
+    for (int i = 0; i < kQuads; ++i) {
+      const int j = i * THREADS + threadIdx.x;
+      if (j < cur.nquad) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = c * v[i][e];
+#pragma unroll
+          for (int k = 0; k < MAXK; ++k) val -= (L.lab[k] == cur.head + 4 * j + e) ? L.wk[k] : 0.0f;
+          o[e] = gscale * val;
+        }
+        __builtin_nontemporal_store(o, g4 + j);
       }
     }
   }
-  if (threadIdx.x == 0) row_loss[r] = loss;
-  if (!GRAD) return;
-  float* g = grad + r * static_cast<long>(V);       // (rows, V) contiguous: same head/tail split as the logits row
-  const float c = wsum / s;
-  if (edge >= 0) {
-    float val = c * ve;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) val -= (lab[k] == edge) ? wk[k] : 0.0f;
-    g[edge] = gscale * val;
+  fold_row_losses<THREADS>(fold, row_loss, rows);
+}
+
+template <bool GRAD, int MAXK, int THREADS>
+static void launch_reg(int variant, long rows, hipStream_t st, const float* logits, const int64_t* labels, int K, int V,
+                       long ignore_index, const float* inv_count, float* grad, float* row_loss, float gscale,
+                       int* flag, const CeFold& fold) {
+  const int grid = static_cast<int>(rows);
+  if (variant == 3 && THREADS == 256)     // 3 workgroups per CU: 168 VGPRs per lane, the 128-register row still fits
+    ce_rows_reg_kernel<GRAD, MAXK, THREADS, (THREADS == 256 ? 3 : 2)><<<grid, THREADS, 0, st>>>(
+        logits, labels, K, rows, V, ignore_index, inv_count, grad, row_loss, gscale, flag, fold);
+  else
+    ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2><<<grid, THREADS, 0, st>>>(
+        logits, labels, K, rows, V, ignore_index, inv_count, grad, row_loss, gscale, flag, fold);
+}
+
+template <int THREADS>
+static void launch_reg_k(bool want_grad, int variant, long rows, hipStream_t st, const float* logits,
+                         const int64_t* labels, int K, int V, long ignore_index, const float* inv_count, float* grad,
+                         float* row_loss, float gscale, int* flag, const CeFold& fold) {
+#define VQA_CE_GO(G, MK) \
+  launch_reg<G, MK, THREADS>(variant, rows, st, logits, labels, K, V, ignore_index, inv_count, grad, row_loss, gscale, \
+                             flag, fold)
+  if (want_grad) {
+    if (K == 1) VQA_CE_GO(true, 1); else if (K <= 4) VQA_CE_GO(true, 4); else VQA_CE_GO(true, 8);
+  } else {
+    if (K == 1) VQA_CE_GO(false, 1); else if (K <= 4) VQA_CE_GO(false, 4); else VQA_CE_GO(false, 8);
   }
-  f32x4* g4 = reinterpret_cast<f32x4*>(g + head);
-#pragma unroll
-  for (int i = 0; i < kQuads; ++i) {
-    const int j = i * THREADS + threadIdx.x;
-    if (j < nquad) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float val = c * v[i][e];
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) val -= (lab[k] == head + 4 * j + e) ? wk[k] : 0.0f;
-        o[e] = gscale * val;
-      }
-      __builtin_nontemporal_store(o, g4 + j);
-    }
-  }
+#undef VQA_CE_GO
 }
 
 }  // namespace vqa
@@ -244,7 +349,9 @@ using namespace vqa;
 
 extern "C" {
 
-int vqa_ce_max_label_sets(void) { return 8; }
+int vqa_ce_max_label_sets(void) { return kCeMaxK; }
+
+int vqa_ce_scratch_floats(void) { return kCeScratchFloats; }
 
 int vqa_ce_set_threads(int threads) {   // reached through vqa_set_option(4, threads)
   if (threads != 256 && threads != 512 && threads != 1024) return VQA_ERR_SHAPE;
@@ -252,38 +359,45 @@ int vqa_ce_set_threads(int threads) {   // reached through vqa_set_option(4, thr
   return VQA_OK;
 }
 
+int vqa_ce_set_variant(int variant) {   // reached through vqa_set_option(5, variant)
+  if (variant != 2 && variant != 3) return VQA_ERR_SHAPE;
+  g_ce_variant = variant;
+  return VQA_OK;
+}
+
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
-                long ignore_index, float* inv_count, float* grad, float* row_loss, float gscale,
-                vqa_stream_t stream) {
-  if (!logits || !labels || !inv_count || !row_loss) return VQA_ERR_NULL;
-  if (K < 1 || K > 8 || rows < 0 || V <= 0 || row_stride < V) return VQA_ERR_SHAPE;
-  if (!aligned4(logits) || (grad && !aligned4(grad))) return VQA_ERR_ALIGN;
-  if (rows == 0) return VQA_OK;
+                long ignore_index, float* scratch, float* grad, float* row_loss, float gscale, float* loss_out,
+                int accumulate, int* flag, vqa_stream_t stream) {
+  if (!logits || !labels || !scratch || !row_loss) return VQA_ERR_NULL;
+  if (K < 1 || K > kCeMaxK || rows < 0 || V <= 0 || row_stride < V) return VQA_ERR_SHAPE;
+  if (!aligned4(logits) || (grad && !aligned4(grad)) || !aligned4(scratch)) return VQA_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ce_count_kernel<<<K, kBlock, 0, st>>>(labels, rows, ignore_index, inv_count);
-  const int grid = static_cast<int>(rows);
+  if (rows == 0) return loss_out ? vqa_sum_partials(row_loss, 0, loss_out, accumulate, gscale, stream) : VQA_OK;
+  ce_count_kernel<<<K, kBlock, 0, st>>>(labels, rows, ignore_index, scratch);
   // register path: row_stride == V keeps the gradient row's alignment phase equal to the logits row's
   const bool reg_path = V >= 8 && V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
   if (reg_path) {
-#define VQA_CE_REG(G, MK, T) \
-  ce_rows_reg_kernel<G, MK, T><<<grid, T, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count, \
-                                                   grad, row_loss, gscale)
-#define VQA_CE_K(G, T) \
-  do { if (K == 1) VQA_CE_REG(G, 1, T); else if (K <= 4) VQA_CE_REG(G, 4, T); else VQA_CE_REG(G, 8, T); } while (0)
-    if (g_ce_threads == 256) { if (grad) VQA_CE_K(true, 256); else VQA_CE_K(false, 256); }
-    else if (g_ce_threads == 512) { if (grad) VQA_CE_K(true, 512); else VQA_CE_K(false, 512); }
-    else { if (grad) VQA_CE_K(true, 1024); else VQA_CE_K(false, 1024); }
-#undef VQA_CE_K
-#undef VQA_CE_REG
+    const CeFold fold{reinterpret_cast<unsigned*>(scratch) + kCeCounterSlot, loss_out, accumulate, gscale};
+    const bool g = grad != nullptr;
+    if (g_ce_threads == 256)
+      launch_reg_k<256>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
+    else if (g_ce_threads == 512)
+      launch_reg_k<512>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
+    else
+      launch_reg_k<1024>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
     return launch_status();
   }
+  const int grid = static_cast<int>(rows);
   if (grad)
-    ce_rows_kernel<true, 8><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count,
-                                                     grad, row_loss, gscale);
+    ce_rows_kernel<true, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, scratch,
+                                                           grad, row_loss, gscale, flag);
   else
-    ce_rows_kernel<false, 8><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, inv_count,
-                                                      grad, row_loss, gscale);
-  return launch_status();
+    ce_rows_kernel<false, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index,
+                                                            scratch, grad, row_loss, gscale, flag);
+  const int rc = launch_status();
+  if (rc != VQA_OK || !loss_out) return rc;
+  if (rows > 0x7fffffffL) return VQA_ERR_SHAPE;
+  return vqa_sum_partials(row_loss, static_cast<int>(rows), loss_out, accumulate, gscale, stream);
 }
 
 }  // extern "C"

@@ -174,7 +174,7 @@ static int launch_stream(const float* s0, const float* s1, const float* s2, floa
   if (vec && n >= 4) {
     const size_t n4 = n / 4;
     const int unroll = TUNABLE ? g_opt_unroll : 4;
-    const int grid = blocks_for(n4, kBlock * unroll, 256 * g_opt_blocks_per_cu);
+    const int grid = blocks_for(n4, kBlock * unroll, cu_count() * g_opt_blocks_per_cu);
     size_t chunk = 0;
     if (g_opt_chunked) {   // equal contiguous chunks, rounded up to whole tiles
       const size_t tile = static_cast<size_t>(kBlock) * unroll;
@@ -203,6 +203,8 @@ using namespace vqa;
 extern "C" {
 
 int vqa_ce_set_threads(int threads);   // ce.hip
+int vqa_ce_set_variant(int variant);   // ce.hip
+int vqa_loss_set_option(int which, int value);   // loss.hip
 
 int vqa_set_option(int option, int value) {
   switch (option) {
@@ -222,6 +224,12 @@ int vqa_set_option(int option, int value) {
       return VQA_OK;
     case 4:
       return vqa_ce_set_threads(value);
+    case 5:
+      return vqa_ce_set_variant(value);
+    case 6:
+    case 7:
+    case 8:
+      return vqa_loss_set_option(option, value);
     default:
       return VQA_ERR_SHAPE;
   }

@@ -245,7 +245,7 @@ int vqa_embed_tokens(const float* word, const float* pos, const float* type, con
   return launch_status();
 }
 
-int vqa_abi_version(void) { return 1; }
+int vqa_abi_version(void) { return 2; }
 
 const char* vqa_error_string(int code) {
   switch (code) {

@@ -265,15 +265,39 @@ _partials = {}
 
 def _partial_buf(device):
     """Per-(device, stream) scratch for the loss partials: launches on one stream are ordered, so reuse is safe."""
+    # zero-initialised: the last word is the arrival counter of the in-kernel fold (the folding workgroup resets it)
     if torch.cuda.is_current_stream_capturing():
         # inside hipGraph capture the scratch must live in that graph's private pool: never cache it
-        return torch.empty(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
+        return torch.zeros(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _partials.get(key)
     if buf is None:
-        buf = torch.empty(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
+        buf = torch.zeros(lib().vqa_neg_cos_partials(), dtype=torch.float32, device=device)
         _partials[key] = buf
     return buf
+
+
+class Workspace:
+    """Scratch tensors one attack call owns and reuses across its iterations: the loss kernels' gradient buffers
+    (4.5 GB per launch at VLMO-base batch 64) and the cross-entropy row buffers.  A buffer handed out here is dead once
+    ``torch.autograd.backward`` has consumed it, i.e. before the next iteration asks again for the same key."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, key, shape, dtype, device):
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(shape, dtype=dtype, device=device)
+        full = (key, tuple(shape), dtype, device)
+        buf = self._bufs.get(full)
+        if buf is None:
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[full] = buf
+        return buf
+
+
+def _scratch(ws, key, shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device) if ws is None else ws.get(key, shape, dtype, device)
 
 
 def _rows_view(t, name):
@@ -299,7 +323,7 @@ def _kernel_ready(t):
     return all(s % 4 == 0 for s in t.stride()[:-1])
 
 
-def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None, weight_period=1):
+def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None, weight_period=1, ws=None):
     """loss_out[0] (+)= gscale * sum_rows -cos(a_row, b_row); returns d(that)/d a (same shape as ``a``) or None.
 
     ``a`` / ``b`` may be strided views (the reference's ``[:, :feat_len, :]`` truncations) as long as rows are
@@ -322,7 +346,7 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
     ga = None
     g0 = g1 = 0
     if want_grad:
-        ga = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+        ga = _scratch(ws, "cos1", a.shape, torch.float32, a.device)
         _, _, _, g0, g1 = _rows_view(ga, "grad")
     if row_weight is not None:
         if row_weight.dtype != torch.uint8 or not row_weight.is_cuda or not row_weight.is_contiguous():
@@ -331,21 +355,30 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
             raise ValueError("row_weight has {} entries, expected weight_period*rows1 = {}".format(
                 row_weight.numel(), weight_period * r1))
     if a.numel() == 0:                 # no rows: zero loss contribution, empty gradient
-        if not accumulate:
+        if not accumulate and loss_out is not None:
             loss_out.zero_()
         return ga
     part = _partial_buf(a.device)
     with _on(a):
         st = stream_for(a)
         check(lib().vqa_neg_cos_rows(ptr(a), ptr(b), ptr(ga), ptr(part), ptr(row_weight), weight_period, r0, r1, d,
-                                     a0, a1, b0, b1, g0, g1, gscale, _COS_EPS, st), "vqa_neg_cos_rows")
-        check(lib().vqa_sum_partials(ptr(part), part.numel(), ptr(loss_out), 1 if accumulate else 0, gscale, st),
-              "vqa_sum_partials")
+                                     a0, a1, b0, b1, g0, g1, gscale, _COS_EPS, ptr(loss_out), 1 if accumulate else 0,
+                                     st), "vqa_neg_cos_rows")      # loss folded by the last workgroup: one launch
     return ga
 
 
+class _Sub:
+    """A view of a Workspace whose keys are prefixed (per-layer fallback launches must not share one buffer)."""
+
+    def __init__(self, ws, tag):
+        self.ws, self.tag = ws, tag
+
+    def get(self, key, shape, dtype, device):
+        return self.ws.get((self.tag, key), shape, dtype, device)
+
+
 def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None,
-                       weight_period=1):
+                       weight_period=1, ws=None):
     """``neg_cos_rows`` over a list of same-shaped feature maps in ONE launch; returns the list of gradients (views of
     one ``(L, ...)`` buffer) or None.  Falls back to per-map launches when the maps do not share shape and strides."""
     n = len(a_list)
@@ -360,14 +393,15 @@ def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_gr
     if not uniform or n == 1:
         grads = []
         for k, (a, b) in enumerate(zip(a_list, b_list)):
-            grads.append(neg_cos_rows(a, b, loss_out, accumulate or k > 0, gscale, want_grad, row_weight, weight_period))
+            grads.append(neg_cos_rows(a, b, loss_out, accumulate or k > 0, gscale, want_grad, row_weight, weight_period,
+                                      ws=None if ws is None else _Sub(ws, k)))
         return grads if want_grad else None
     r0, r1, d, sa0, sa1 = _rows_view(a0, "out")
     _, _, _, sb0, sb1 = _rows_view(b0, "y")
     ga = None
     g0 = g1 = 0
     if want_grad:
-        ga = torch.empty((n,) + tuple(a0.shape), dtype=torch.float32, device=a0.device)
+        ga = _scratch(ws, "cosN", (n,) + tuple(a0.shape), torch.float32, a0.device)
         _, _, _, g0, g1 = _rows_view(ga[0], "grad")
     if row_weight is not None:
         if row_weight.dtype != torch.uint8 or not row_weight.is_cuda or not row_weight.is_contiguous():
@@ -383,17 +417,19 @@ def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_gr
     with _on(a0):
         st = stream_for(a0)
         check(lib().vqa_neg_cos_rows_multi(pa, pb, pg, n, ptr(part), ptr(row_weight), weight_period, r0, r1, d, sa0, sa1,
-                                           sb0, sb1, g0, g1, gscale, _COS_EPS, st), "vqa_neg_cos_rows_multi")
-        check(lib().vqa_sum_partials(ptr(part), part.numel(), ptr(loss_out), 1 if accumulate else 0, gscale, st),
-              "vqa_sum_partials")
+                                           sb0, sb1, g0, g1, gscale, _COS_EPS, ptr(loss_out), 1 if accumulate else 0,
+                                           st), "vqa_neg_cos_rows_multi")
     return [ga[i] for i in range(n)] if want_grad else None
 
 
-def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want_grad=True, ignore_index=-100):
+def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want_grad=True, ignore_index=-100,
+                      flag=None, ws=None):
     """loss_out[0] (+)= gscale * sum_k CE_mean(logits, label_sets[k]); returns d(that)/d logits or None.
 
     ``logits`` (..., V) fp32 with dense rows; ``label_sets`` int64 (K, rows) -- K label sets over the same rows
     (K = 1 for the reference's 2-d labels, K = labels.shape[1] for its 3-d labels).
+    A label outside ``[0, V)`` that is not ``ignore_index`` makes the loss NaN and sets ``VQA_FLAG_BAD_LABEL`` in
+    ``flag`` (int32 device word, optional) -- torch device-asserts there; nothing is silently dropped.
     """
     dev_f32(logits, "logits", contiguous=False)
     v = logits.shape[-1]
@@ -407,15 +443,13 @@ def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want
     k = label_sets.shape[0]
     if k > lib().vqa_ce_max_label_sets():
         raise _hip.HipExtensionError("at most {} label sets per launch".format(lib().vqa_ce_max_label_sets()))
-    grad = torch.empty((rows, v), dtype=torch.float32, device=logits.device) if want_grad else None
-    inv_count = torch.empty(k, dtype=torch.float32, device=logits.device)
-    row_loss = torch.empty(max(rows, 1), dtype=torch.float32, device=logits.device)
+    grad = _scratch(ws, "ce_grad", (rows, v), torch.float32, logits.device) if want_grad else None
+    scratch = _scratch(ws, "ce_scratch", (lib().vqa_ce_scratch_floats(),), torch.float32, logits.device)
+    row_loss = _scratch(ws, "ce_rows", (max(rows, 1),), torch.float32, logits.device)
     with _on(logits):
-        st = stream_for(logits)
         check(lib().vqa_ce_rows(ptr(flat), flat.stride(0), ctypes.c_void_p(label_sets.data_ptr()), k, rows, v,
-                                ignore_index, ptr(inv_count), ptr(grad), ptr(row_loss), gscale, st), "vqa_ce_rows")
-        check(lib().vqa_sum_partials(ptr(row_loss), rows, ptr(loss_out), 1 if accumulate else 0, gscale, st),
-              "vqa_sum_partials")
+                                ignore_index, ptr(scratch), ptr(grad), ptr(row_loss), gscale, ptr(loss_out),
+                                1 if accumulate else 0, ptr(flag), stream_for(logits)), "vqa_ce_rows")
     return grad.reshape(logits.shape) if want_grad else None
 
 
