@@ -21,8 +21,11 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# the host driver only supports dmabuf IPC: must be in the environment BEFORE the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -86,9 +89,9 @@ def build_models(args, cfg, device):
     return "vlmo", white, black, VlmoAttackAdapters(white), cfg.max_text_len
 
 
-# HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
-# separate rocprofv3 runs, tools/pmc_step.py + tools/pmc_summary.py), keyed by elements per launch
-PMC_TRAFFIC_BYTES = {64 * 3 * 384 * 384: (165923 * 2 + 110592) * 1024, 256 * 3 * 384 * 384: (663589 * 2 + 442368) * 1024}
+# HBM traffic per launch is NOT measured by this script (PMC counters need their own rocprofv3 passes): the tracked
+# summary below holds FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch for the kernels timed here.
+PMC_SUMMARY = "profiles/r02/pmc_hot_kernels_summary.txt"
 
 
 class KernelTimer:
@@ -97,8 +100,8 @@ class KernelTimer:
 
     def __init__(self):
         self.step_events, self.step_numel = [], 0
-        self.loss_events, self.loss_bytes = [], []
-        self._live = {}
+        self.loss_events, self.loss_rows = [], []
+        self._live = {}      # id(weight plane) -> (plane kept alive, device-side count of live rows): no host read here
 
     def install(self):
         from vqattack_amd import ops
@@ -123,12 +126,13 @@ class KernelTimer:
             w = kw.get("row_weight")
             a_ = a_list[0]
             rows = a_.numel() // a_.shape[-1]
-            if w is not None:                 # live (weight != 0) rows; one host read per distinct weight plane
-                key = (w.data_ptr(), w.numel())
-                if key not in timer._live:
-                    timer._live[key] = int((w != 0).sum().item())
-                rows = timer._live[key] * (rows // w.numel())
-            timer.loss_bytes.append((12 if out is not None else 8) * rows * a_.shape[-1] * len(a_list))
+            live, per = None, 1
+            if w is not None:                 # live (weight != 0) rows, counted on the device, read after the timed region
+                if id(w) not in timer._live:  # the plane is kept alive, so its id cannot be recycled for another mask
+                    timer._live[id(w)] = (w, (w != 0).sum())
+                live, per = timer._live[id(w)][1], rows // w.numel()
+            timer.loss_rows.append((live if live is not None else rows, per,
+                                    (12 if out is not None else 8) * a_.shape[-1] * len(a_list)))
             return out
         ops.linf_step, ops.neg_cos_rows_multi = timed_step, timed_loss
 
@@ -150,21 +154,24 @@ class KernelTimer:
         gbs = nbytes / mean_ms / 1e6
         step = dict(kernel="vqa_linf_step (stream4_kernel<StepOp>)", bound="hbm", achieved=round(gbs, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                    traffic=PMC_TRAFFIC_BYTES.get(self.step_numel), launches=n,
+                    traffic=None, traffic_source=PMC_SUMMARY, launches=n,
                     mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
                     algorithmic_bytes_per_launch=nbytes,
-                    timing="hip events on the launch stream, per launch; traffic = PMC bytes per launch (profiles/r01)")
+                    timing="hip events on the launch stream, per launch; HBM traffic is not measured in this run "
+                           "(separate rocprofv3 --pmc passes, summary in traffic_source)")
         loss = None
         mean_ms, min_ms, n = self._stats(self.loss_events)
         if n:
-            total_bytes = sum(self.loss_bytes)           # launches differ in size (text / image rows): bytes over time
+            # launches differ in size (text / image rows): total bytes over total time; live-row counts read only now
+            total_bytes = sum(int(rows) * per * row_bytes for rows, per, row_bytes in self.loss_rows)
             gbs = total_bytes / (mean_ms * n) / 1e6
-            loss = dict(kernel="vqa_neg_cos_rows_multi (+ vqa_sum_partials), all layers of a modality per launch", bound="hbm", achieved=round(gbs, 1),
+            loss = dict(kernel="vqa_neg_cos_rows_multi (neg_cos_rows_kernel: every per-layer map of a modality in one "
+                               "launch, loss folded in the launch)", bound="hbm", achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
-                        algorithmic_bytes_per_launch=round(total_bytes / n),
-                        note="12*D bytes per live row (read a, b; write grad); the event pair also covers the "
-                             "5 us partial-sum kernel and the gradient buffer allocation")
+                        algorithmic_bytes_per_launch=round(total_bytes / n), traffic=None, traffic_source=PMC_SUMMARY,
+                        note="12*D bytes per live row (read a, b; write grad); padded text rows are neither read nor "
+                             "counted")
         return step, loss
 
 
@@ -192,6 +199,18 @@ def step_kernel_microbench(batch, image_size, reps=40):
     return dict(kernel="vqa_linf_step", batch=batch, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), mean_launch_us=round(ms * 1e3, 2),
                 algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps))
+
+
+def baseline_config(args):
+    """Which entry of BASELINE.json's ``configs`` the run is (the default run is configs[1])."""
+    full = args.pgd_steps == 40 and args.image_size == 384
+    if full and args.model == "vlmo_base" and not args.joint and args.batch == 64:
+        return "BASELINE configs[1]" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "BASELINE configs[3] shape"
+    if full and args.model == "albef_base" and not args.joint and args.batch == 256:
+        return "BASELINE configs[2]"
+    if full and args.model == "vlmo_large" and args.joint and args.batch == 128:
+        return "BASELINE configs[4] workload"
+    return "not a BASELINE config"
 
 
 def usable_cores():
@@ -322,14 +341,16 @@ def main():
             "metric": "adversarial_vqa_examples_per_sec", "value": round(total / dt, 4), "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "{} VQAttack {} (BASELINE configs[{}]): batch {} per GPU, {} PGD steps, "
-                                   "{}x{} images, {}-token questions, eps 0.125 step 0.01 L-inf clip [-1,1], random start, "
-                                   "black-box scoring + ASR gather".format(
+            "config": {"workload": "{} VQAttack {} ({}): batch {} per GPU, {} PGD steps, {}x{} images, questions of "
+                                   "{} real tokens ([CLS] + {} words + [SEP]) padded to {}{}, eps 0.125 step 0.01 L-inf "
+                                   "clip [-1,1], random start, black-box scoring + ASR gather".format(
                                        args.model, "joint image+text attack ({} words)".format(args.joint)
-                                       if args.joint else "image PGD", 4 if args.joint else 1, args.batch,
-                                       args.pgd_steps, cfg.image_size, cfg.image_size, text_len),
+                                       if args.joint else "image PGD", baseline_config(args), args.batch,
+                                       args.pgd_steps, cfg.image_size, cfg.image_size, n_body + 2, n_body, text_len,
+                                       " (the all-padding columns are not run through the encoder)"
+                                       if flavor == "vlmo" else ""),
                        "batch_per_gpu": args.batch, "pgd_steps": args.pgd_steps, "image_size": cfg.image_size,
-                       "text_len": text_len, "substitutable_words": args.joint,
+                       "text_len": text_len, "real_tokens": n_body + 2, "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
             "roofline": roof,

@@ -3,8 +3,11 @@ import json
 import os
 import sys
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC only on this host driver: the variable is read once, when the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -21,7 +24,6 @@ def init_distributed():
         raise SystemExit("the attack path runs on MI355X GPUs only (no CPU fallback)")
     torch.cuda.set_device(local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     return rank, world, torch.device("cuda", local)
 

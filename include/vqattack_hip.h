@@ -180,12 +180,15 @@ int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate
                      vqa_stream_t stream);
 
 /* Masked-LM cross entropy with ignore_index over K label sets, loss and gradient in one launch:
- *   loss = sum_k mean_{r : labels[k][r] != ignore} ( logsumexp(logits[r,:]) - logits[r, labels[k][r]] )
+ *   loss = sum_g sum_k mean_{r in group g : labels[k][r] != ignore} ( logsumexp(logits[r,:]) - logits[r, labels[k][r]] )
+ * rows_per_group == 0: ONE group = F.cross_entropy's mean over all rows (the reference's op on whatever batch it is
+ * given); rows_per_group == L: one group per SAMPLE of a (B*L)-row batch = the batch-1 reference's loss summed over
+ * the samples, whose per-sample gradients equal the batch-1 gradients whatever the other samples' labels are.
  * row_loss[r] (scratch, `rows` floats) receives row r's share; loss_out (nullable) receives
  *   loss_out[0] = (accumulate ? loss_out[0] : 0) + gscale * sum_r row_loss[r]      (summed in row order, in the launch);
  * grad (nullable, (rows, V) contiguous) receives gscale * d loss / d logits.  labels is int64 [K][rows];
- * scratch holds vqa_ce_scratch_floats() floats (reciprocal valid counts + the fold's arrival counter; the launch
- * initialises it).  K <= vqa_ce_max_label_sets().
+ * scratch holds vqa_ce_scratch_floats(K, groups) floats (the fold's arrival counters + reciprocal valid counts per label
+ * set and group; the launch initialises it).  K <= vqa_ce_max_label_sets().
  * A label that is neither ignore_index nor in [0, V) makes the loss NaN and ORs VQA_FLAG_BAD_LABEL into *flag
  * (flag nullable); torch raises a device assert for it, it is never silently ignored.
  * exp() is the hardware exponential (v_exp_f32, ~2 ulp); parity with torch is stated as 1e-4 relative in the tests.
@@ -193,10 +196,10 @@ int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate
  * 3-d labels and the autograd backward: A-ch/attacks/fast_gradient_method.py:131-142, V-ch/...:115-126.
  * Algorithmic bytes: 8*V per row (read the logits once from HBM, write the gradient once). */
 int vqa_ce_max_label_sets(void);
-int vqa_ce_scratch_floats(void);
+long vqa_ce_scratch_floats(int K, long groups);
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
-                long ignore_index, float* scratch, float* grad, float* row_loss, float gscale, float* loss_out,
-                int accumulate, int* flag, vqa_stream_t stream);
+                long ignore_index, long rows_per_group, float* scratch, float* grad, float* row_loss, float gscale,
+                float* loss_out, int accumulate, int* flag, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- text side
  * dst[b, k, :] = src[b, idx[k], :]  for src (B, L, D), idx int64[K] with 0 <= idx[k] < L.
@@ -223,6 +226,22 @@ int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, con
  * triples int32 [n][3]; D multiple of 4, <= 2048; the caller guarantees rows are distinct and in range. */
 int vqa_embed_tokens(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                      float ln_eps, const int32_t* triples, int n, float* dst, int D, vqa_stream_t stream);
+
+/* Greedy acceptance of the word substitutions of one probe step, for the whole batch, on the device
+ * (update_adv_text's sort + acceptance loop, ALBEF_attack/adv_attack.py:299-323; vlmo_module.py:1676-1700), with the
+ * bag-of-embeddings stand-in for the reference's TF-Hub sentence encoder (:315-318):
+ *   sim(ids) = <m(ori), m(ids)> / (|m(ori)| |m(ids)| + 1e-12),  m(ids) = mean over non-pad (id != 0) tokens of table[id].
+ * cand int32 [n][4] = {sample, position, grad row, vocabulary id} (as for vqa_cand_dir_sim); order int32 [n] lists the
+ * candidate indices grouped by sample and, within a sample, by descending dir_sim score (stable); seg int32 [B + 1]:
+ * order[seg[s] .. seg[s+1]) belong to sample s.  Per sample, in that order: skip a candidate whose position already
+ * took a substitution; accept it iff the similarity between the ORIGINAL question and the current question with that
+ * position replaced exceeds the threshold, which then rises to that similarity.
+ * ori_ids, cur_ids int64 (B, L), L <= 64; cur_ids is updated in place; new_id int32 (B, L) receives the accepted id per
+ * position or -1, acc_rank (nullable, int32 (B, L)) the order in which the sample accepted it (0, 1, ...) or -1.
+ * table fp32 (V, E), E <= 512.  One wavefront per sample. */
+int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* seg, int B, int L,
+                      const int64_t* ori_ids, int64_t* cur_ids, int32_t* new_id, int32_t* acc_rank, const float* table,
+                      int V, int E, float threshold, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- input pipeline
  * Pillow-exact bicubic resize of an 8-bit interleaved image (H, W, C), C <= 4, then ToTensor + Normalize into planar

@@ -3,8 +3,12 @@
 The shipped adapters (``vqattack_amd/whitebox``) are batched and never pack features; the reference's are batch-1 and
 pack with ``torch.stack`` / ``torch.cat``.  These closures restate the reference's packing over the SAME frozen encoder
 object so that (a) the oracle's loss sees exactly the tensors the reference's FGM would see and (b) bench.py's
-``cpu_baseline`` times the reference's own structure.  Restated from source text (the orchestrators cannot be imported
-here), hence **parity unpinned** for the packing itself; the arithmetic downstream is the pinned oracle.
+``cpu_baseline`` times the reference's own structure.
+
+**Pinned**: the VLMo packing by the ``pack_vlmo_*`` arrays of ``tests/golden/text_golden.npz`` -- the reference's own
+``pgd_attack`` / ``pgd_attack_vl`` / ``pgd_mlm_attack`` / ``Gen_ori_feats`` methods compiled from its source and executed
+over this repository's tiny VLMo (``tests/golden/make_text_golden_tasks.py``); both packings by the ``loop_*`` cases,
+which run the reference's whole per-sample loop through these shapes (``tests/test_text_golden_loops.py``).
 
   * VLMO:  ``pgd_attack`` vlmo_module.py:1387-1446, ``pgd_attack_vl`` :1328-1385, ``pgd_mlm_attack`` :1448-1529,
            ``Gen_ori_feats`` :1287-1312
@@ -17,29 +21,32 @@ import torch
 class VlmoRefAdapters:
     """Batch 1 only (the reference indexes ``[0]``)."""
 
-    def __init__(self, model, text_ids, text_masks):
+    def __init__(self, model, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
         assert text_ids.shape[0] == 1
         self.m, self.ids, self.masks = model, text_ids, text_masks
+        # self.batch["text_ids_mlm"] / ["text_mask_mlm"]: the [MASK]-ed paraphrase the MLM closure reads (:1457-1458)
+        self.ids_mlm = text_ids if text_ids_mlm is None else text_ids_mlm
+        self.masks_mlm = text_masks if text_mask_mlm is None else text_mask_mlm
 
-    def _pack(self, feats, states):
+    def _pack(self, feats, states, masks):
         stacked = torch.stack(feats, axis=1)                         # (1, depth+1, T+N, D)
-        tlen = self.m.cfg.max_text_len
+        tlen = self.m.cfg.max_text_len                               # the reference's literal 40
         img = stacked[0, :, tlen:]
-        keep = torch.where(self.masks[0] == 1)[0]
+        keep = torch.where(masks[0] == 1)[0]
         txt = stacked[0, :, keep]
         return [self.m.pooled(states), stacked[0, :, 0, :], torch.cat([txt, img], axis=1)]
 
     def pgd_attack(self, x):
         feats, states = self.m.encode(x, self.m.text_embeddings(self.ids), self.masks)
-        return self._pack(feats, states)
+        return self._pack(feats, states, self.masks)
 
     def pgd_attack_vl(self, xs):
         feats, states = self.m.encode(xs[0], xs[1], self.masks)
-        return self._pack(feats, states)
+        return self._pack(feats, states, self.masks)
 
     def pgd_mlm_attack(self, x):
-        feats, states = self.m.encode(x, self.m.text_embeddings(self.ids), self.masks)
-        packed = self._pack(feats, states)
+        feats, states = self.m.encode(x, self.m.text_embeddings(self.ids_mlm), self.masks_mlm)
+        packed = self._pack(feats, states, self.masks_mlm)
         return [self.m.mlm_score(states[:, :self.m.cfg.max_text_len]), packed[1], packed[2]]
 
     def gen_ori_feats(self, image):
@@ -49,8 +56,10 @@ class VlmoRefAdapters:
 
 
 class AlbefRefAdapters:
-    def __init__(self, model, text_ids, text_masks):
+    def __init__(self, model, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None):
         self.m, self.ids, self.masks = model, text_ids, text_masks
+        self.ids_mlm = text_ids if text_ids_mlm is None else text_ids_mlm
+        self.masks_mlm = text_masks if text_mask_mlm is None else text_mask_mlm
 
     def pgd_attack(self, x):
         img, txt = self.m.gen_feats(x, self.ids, self.masks)
@@ -61,7 +70,7 @@ class AlbefRefAdapters:
         return [torch.cat(txt, axis=0), torch.cat(img, axis=0)]
 
     def pgd_mlm_attack(self, x):
-        return [self.m.get_mlm_logits(x, self.ids, self.masks)]
+        return [self.m.get_mlm_logits(x, self.ids_mlm, self.masks_mlm)]
 
     def gen_ori_feats(self, image):
         with torch.no_grad():

@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-rank GPU tests start their ranks through a fork server that is launched HERE, before anything in this
+    # process touches the GPU: a process that has initialised HIP must never exec another program on the GPU boxes, and
+    # the ranks must not inherit an initialised runtime either.  The server itself imports nothing GPU-related; every
+    # rank is forked from it and initialises the GPU on its own.
+    try:
+        import multiprocessing
+        from multiprocessing import forkserver
+        multiprocessing.get_context("forkserver")
+        forkserver.set_forkserver_preload([])
+        forkserver.ensure_running()
+    except (ImportError, ValueError, OSError):
+        pass
 
 
 @pytest.fixture(scope="session", autouse=True)

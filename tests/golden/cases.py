@@ -77,6 +77,11 @@ ATTACK_CASES = [
          labels="2d"),
     dict(name="vlmo_pgdvl", flavor="vlmo", op="pgd_vl", batch=1, steps=1, eps=0.125, eps_iter=0.01,
          norm="inf", ls=1, time=1, start_inside=True, mask=[1, 2, 5]),
+    # fast_gradient_method of the *_vl modules called directly (row a6): image step + text_embeds.grad[:, text_emb_pick]
+    dict(name="albef_fgmvl", flavor="albef", op="fgm_vl", batch=2, eps=0.01, norm="inf", ls=1, mask=[0, 2, 5]),
+    dict(name="albef_fgmvl_targeted_l2", flavor="albef", op="fgm_vl", batch=2, eps=0.7, norm=2, ls=1, mask=[3],
+         targeted=True),
+    dict(name="vlmo_fgmvl", flavor="vlmo", op="fgm_vl", batch=1, eps=0.01, norm="inf", ls=1, mask=[1, 4]),
 ]
 
 ALL_CASES = UTIL_CASES + ATTACK_CASES
@@ -123,7 +128,7 @@ def _labels(kind, batch, length, device):
 
 def attack_inputs(case, device="cpu"):
     toy = ToyWhiteBox(device=device)
-    x0, eta = toy_inputs(case["batch"], eps=case["eps"] if case["op"] != "fgm" else 0.05)
+    x0, eta = toy_inputs(case["batch"], eps=case["eps"] if case["op"] not in ("fgm", "fgm_vl") else 0.05)
     x0, eta = x0.to(device), eta.to(device)
     start = torch.clamp(x0 + eta, -1, 1) if case.get("start_inside", True) else x0.clone()
     extra = case.get("y_extra", 0)
@@ -188,6 +193,12 @@ def run_case(impl, case, device="cpu"):
             kw["y"] = [lab, feats[1], feats[2], syn]
         adv, loss = impl.fgm(flavor)(fn, start, case["eps"], norm, x0, **kw)
         return {"adv": adv.detach(), "loss": loss.detach().reshape(1)}
+
+    if case["op"] == "fgm_vl":
+        emb = toy.embed_text(toy.text_ids.expand(case["batch"], -1)).clone()
+        adv, tgrad = impl.fgm_vl(flavor)(vl_fn, [start, emb], case["eps"], norm, x0, y=y_feat, ls=ls,
+                                          targeted=case.get("targeted", False), text_emb_pick=case["mask"], **clip)
+        return {"adv": adv.detach(), "text_grad": tgrad.detach()}
 
     kw = dict(ori_x=x0, time=case["time"], ls=ls, **clip)
     init_eta = None

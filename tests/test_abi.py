@@ -58,8 +58,8 @@ def test_argument_validation_returns_error_codes_without_touching_a_gpu():
     assert lib.vqa_neg_cos_rows(p, p, null, p, null, 1, 2, 2, 4096, 0, 0, 0, 0, 0, 0, 1.0, 1e-6, null, 0, null) == ERR_SHAPE  # D > 2048
     assert lib.vqa_neg_cos_rows(p, p, null, p, null, 1, 2, 2, 8, 18, 8, 16, 8, 0, 0, 1.0, 1e-6, null, 0, null) == ERR_SHAPE   # stride % 4
     assert lib.vqa_neg_cos_rows(p, p, null, null, null, 1, 2, 2, 8, 16, 8, 16, 8, 0, 0, 1.0, 1e-6, null, 0, null) == ERR_NULL
-    assert lib.vqa_ce_rows(p, 8, p, 9, 2, 8, -100, p, null, p, 1.0, null, 0, null, null) == ERR_SHAPE           # K > 8
-    assert lib.vqa_ce_rows(p, 4, p, 1, 2, 8, -100, p, null, p, 1.0, null, 0, null, null) == ERR_SHAPE           # row stride < V
+    assert lib.vqa_ce_rows(p, 8, p, 9, 2, 8, -100, 0, p, null, p, 1.0, null, 0, null, null) == ERR_SHAPE           # K > 8
+    assert lib.vqa_ce_rows(p, 4, p, 1, 2, 8, -100, 0, p, null, p, 1.0, null, 0, null, null) == ERR_SHAPE           # row stride < V
     assert lib.vqa_gather_rows(p, null, p, 1, 4, 2, 8, null) == ERR_NULL
     assert lib.vqa_cand_dir_sim(p, p, p, p, p, 1e-12, p, p, p, p, 1, 4, 2, 6, null) == ERR_SHAPE
     assert lib.vqa_embed_tokens(p, p, p, p, p, 1e-12, null, 1, p, 8, null) == ERR_NULL
@@ -67,6 +67,6 @@ def test_argument_validation_returns_error_codes_without_touching_a_gpu():
     assert lib.vqa_resize_bicubic_v_normalize(p, 4, 4, 3, null, null, 0, 8, 0.5, 0.5, p, null) == ERR_NULL   # needs taps
     assert lib.vqa_resize_bicubic_v_normalize(p, 4, 4, 3, p, p, 5, 8, 0.5, 0.0, p, null) == ERR_SHAPE        # std == 0
     assert lib.vqa_set_option(2, 3) == ERR_SHAPE and lib.vqa_set_option(4, 100) == ERR_SHAPE
-    assert lib.vqa_set_option(5, 7) == ERR_SHAPE and lib.vqa_set_option(8, 3) == ERR_SHAPE and lib.vqa_ce_scratch_floats() >= lib.vqa_ce_max_label_sets() + 1
+    assert lib.vqa_set_option(5, 7) == ERR_SHAPE and lib.vqa_set_option(8, 3) == ERR_SHAPE and lib.vqa_ce_scratch_floats(8, 64) >= 8 * 64 + 1 and lib.vqa_ce_scratch_floats(0, 1) == 0
     for code in (ERR_NULL, ERR_SHAPE, ERR_ALIGN):
         assert lib.vqa_error_string(code)

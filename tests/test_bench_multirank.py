@@ -1,0 +1,71 @@
+"""bench.py's N > 1 flow, rehearsed with two ranks that share the one GPU of the test box.
+
+The driver launches the real thing as ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` with
+one GPU per rank over RCCL; here the two ranks are forked from the pre-GPU fork server of ``tests/conftest.py`` (no exec
+from a GPU-initialised process), read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from their environment exactly like
+under torchrun, and use ``VQA_DIST_BACKEND=gloo`` so that both can sit on ``cuda:0`` (the collectives then run on host
+tensors; the RCCL branch of bench.py is untouched).  Checked: rank 0 prints ONE JSON line for n_gpus = 2 whose value is
+the aggregate over both ranks (2 x batch x steps / max-over-ranks time) and whose ASR was gathered from both ranks.
+"""
+import json
+import multiprocessing
+import os
+import socket
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench_rank(rank, world, port, out_path, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), VQA_DIST_BACKEND="gloo")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py"] + list(argv)
+    with open(out_path, "w") as out:
+        os.dup2(out.fileno(), 1)                      # the JSON line goes to the file, whoever prints it
+        import bench
+        bench.main()
+        sys.stdout.flush()
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    ctx = multiprocessing.get_context("forkserver")
+    world, batch, steps = 2, 4, 2
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", "1", "--model", "vlmo_tiny", "--batch", str(batch),
+            "--pgd-steps", "6", "--no-cpu-baseline", "--no-b256"]
+    port = _free_port()
+    outs = [str(tmp_path / "rank{}.out".format(r)) for r in range(world)]
+    procs = [ctx.Process(target=_bench_rank, args=(r, world, port, outs[r], argv)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join()
+            pytest.fail("a bench rank did not finish within 300 s")
+        assert p.exitcode == 0
+    lines = [ln for ln in open(outs[0]).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line"
+    assert not [ln for ln in open(outs[1]).read().splitlines() if ln.startswith("{")], "only rank 0 reports"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["metric"] == "adversarial_vqa_examples_per_sec" and rec["unit"] == "examples/s"
+    assert rec["config"]["batch_per_gpu"] == batch
+    # whole-job aggregate over the max-over-ranks time: value = world * batch * steps / (ms_per_step * steps)
+    assert abs(rec["value"] - world * batch / (rec["ms_per_step"] / 1e3)) <= 0.02 * rec["value"]
+    asr = rec["attack_success_rate"]
+    assert asr is not None and 0.0 <= asr <= 1.0
+    assert abs(asr * world * batch * steps - round(asr * world * batch * steps)) < 1e-4, "ASR is over 2 x batch x steps bits"
+    assert rec["roofline"] is not None and rec["roofline"]["launches"] == 6 * steps and rec["vs_baseline"] is None

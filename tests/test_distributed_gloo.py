@@ -60,3 +60,75 @@ def test_single_rank_ledger():
     assert led.all_gather_rate() is None
     led.record(torch.tensor([True, False, True, True]))
     assert led.all_gather_rate() == 0.75
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# run_sweep's whole N > 1 flow on CPU: interleaved shards, uneven (schedule, loss-mode) buckets, ragged last batches,
+# per-rank ledger, all-gather of bits + ids.  The attack and the black box are stand-ins (the real ones need the GPU);
+# the success bit of a sample is a pure function of its id so that the gathered ASR has a known value.
+class _FakeAttack:
+    class cfg:
+        budget = 40
+
+    def __init__(self):
+        self.calls = []
+
+    def _result(self, images, text_ids, attackable, per_sample_steps):
+        from vqattack_amd.attack.runner import BatchResult
+        adv_ids = text_ids.clone()
+        adv_ids[:, 1] = -adv_ids[:, 1]                         # mark the first body token as "substituted"
+        self.calls.append(images.shape[0])
+        return BatchResult(adv_images=images + 0.01, adv_text_ids=adv_ids, gradient_steps=per_sample_steps)
+
+    def attack_batch(self, images, text_ids, text_masks, attackable, dual=False, tasks=None, **_kw):
+        n_words = int(attackable[0].sum())
+        assert bool((attackable.sum(dim=1) == n_words).all()), "a batch must be schedule-pure"
+        if dual:
+            assert tasks is not None and all(t.old_alg == 0 for t in tasks) and len(tasks) == images.shape[0]
+        return self._result(images, text_ids, attackable, 40 + n_words)
+
+    def attack_mixed(self, images, text_ids, text_masks, attackable, **_kw):
+        return self._result(images, text_ids, attackable, int((40 + attackable.sum(dim=1)).sum()))
+
+
+class _FakeBlack:
+    """The answer changes under the fake attack iff the ORIGINAL first body token id is divisible by 3."""
+
+    def vqa_answer(self, images, text_ids, text_masks):
+        t = text_ids[:, 1]
+        return ((t < 0) & ((-t) % 3 == 0)).long()
+
+
+def _sweep_worker(rank, world, port, n_samples, mixed, out_dir):
+    from vqattack_amd.attack.sweep import run_sweep
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake = _FakeAttack()
+        res = run_sweep("vlmo", None, _FakeBlack(), None, n_samples=n_samples, batch=4, image_size=8, text_len=12,
+                        device="cpu", rank=rank, world=world, log_every=0, max_words=5, dual_every=3, mixed=mixed,
+                        attack=fake)
+        torch.save({"asr": res["asr"], "n_local": res["n_local"], "steps": res["gradient_steps"],
+                    "qids": sorted(map(int, res["adv_text"])), "calls": fake.calls},
+                   os.path.join(out_dir, "s{}.pt".format(rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("n_samples", [23, 10])
+def test_two_rank_sweep_shard_ledger_gather(tmp_path, n_samples, mixed):
+    from vqattack_amd.attack.sweep import synthetic_questions
+    world = 2
+    mp.spawn(_sweep_worker, args=(world, _free_port(), n_samples, mixed, str(tmp_path)), nprocs=world, join=True)
+    ids, _, att = synthetic_questions(n_samples, 12, seed=0, max_words=5)
+    want_asr = float((ids[:, 1] % 3 == 0).float().mean())
+    got = [torch.load(os.path.join(str(tmp_path), "s{}.pt".format(r))) for r in range(world)]
+    assert sorted(got[0]["qids"] + got[1]["qids"]) == list(range(n_samples))        # every sample attacked exactly once
+    assert got[0]["qids"] == list(range(0, n_samples, 2)) and got[1]["qids"] == list(range(1, n_samples, 2))
+    for r in range(world):
+        assert abs(got[r]["asr"] - want_asr) < 1e-6                                 # same gathered rate on every rank
+        assert got[r]["n_local"] == len(got[r]["qids"])
+        assert max(got[r]["calls"]) <= 4 and sum(got[r]["calls"]) == got[r]["n_local"]   # ragged batches, none lost
+    assert got[0]["steps"] + got[1]["steps"] == int((40 + att.sum(dim=1)).sum())

@@ -450,3 +450,118 @@ def test_neg_cos_rows_multi_equals_per_layer_launches():
     g_fb = ops.neg_cos_rows_multi(a_mixed, b, many, accumulate=False, gscale=0.5, row_weight=w, weight_period=3)
     for x, y in zip(g_one, g_fb):
         assert torch.equal(x, y)
+
+
+def test_in_kernel_loss_fold_is_reproducible_and_equals_the_two_launch_form():
+    """The last-arriving workgroup folds the partials in index order: same bits run to run, and the same value as
+    partials + vqa_sum_partials."""
+    from vqattack_amd import _hip
+    ops = _ops()
+    r = np.random.RandomState(91)
+    a = torch.from_numpy(r.standard_normal((64, 617, 768)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(r.standard_normal((64, 617, 768)).astype(np.float32)).to(DEV)
+    slot = torch.zeros(1, device=DEV)
+    vals = []
+    for _ in range(5):
+        ops.neg_cos_rows(a, b, slot, accumulate=False)
+        vals.append(slot.clone())
+    assert all(torch.equal(v, vals[0]) for v in vals)
+    # partials-only launch + explicit fold through the C ABI
+    part = torch.zeros(_hip.lib().vqa_neg_cos_partials(), device=DEV)
+    ga = torch.empty_like(a)
+    lib = _hip.lib()
+    _hip.check(lib.vqa_neg_cos_rows(_hip.ptr(a), _hip.ptr(b), _hip.ptr(ga), _hip.ptr(part), None, 1, 64, 617, 768,
+                                    617 * 768, 768, 617 * 768, 768, 617 * 768, 768, 1.0, 1e-6, None, 0,
+                                    _hip.stream_for(a)), "vqa_neg_cos_rows")
+    two = torch.zeros(1, device=DEV)
+    _hip.check(lib.vqa_sum_partials(_hip.ptr(part), part.numel(), _hip.ptr(two), 0, 1.0, _hip.stream_for(a)), "sum")
+    assert torch.allclose(two, vals[0], rtol=1e-6)
+    # accumulate on top of an existing slot value
+    slot.fill_(3.0)
+    ops.neg_cos_rows(a, b, slot, accumulate=True, want_grad=False)
+    assert torch.allclose(slot, vals[0] + 3.0, rtol=1e-6)
+
+
+def test_mlm_cross_entropy_flags_out_of_range_labels():
+    """A label that is neither ignore_index nor in [0, V): NaN loss + VQA_FLAG_BAD_LABEL (torch device-asserts)."""
+    from vqattack_amd import _hip
+    ops = _ops()
+    logits = torch.randn(6, 30522, device=DEV)
+    labels = torch.tensor([[5, -100, 30522, 7, -100, 9]], device=DEV)
+    slot, flag = torch.zeros(1, device=DEV), ops.new_flag(DEV)
+    g = ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, flag=flag)
+    assert torch.isnan(slot).all() and int(flag.item()) & _hip.VQA_FLAG_BAD_LABEL
+    assert torch.isfinite(g[[0, 1, 3, 4, 5]]).all()
+    labels[0, 2] = -7
+    slot.zero_(), flag.zero_()
+    ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, flag=flag, want_grad=False)
+    assert torch.isnan(slot).all() and int(flag.item()) & _hip.VQA_FLAG_BAD_LABEL
+    labels[0, 2] = -100
+    slot.zero_(), flag.zero_()
+    ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, flag=flag)
+    assert torch.isfinite(slot).all() and int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_mlm_cross_entropy_per_sample_normalisation(k):
+    """rows_per_sample = L: the loss is the SUM over samples of the batch-1 reference loss (each sample's label sets
+    divided by that sample's own valid counts), gradients per sample equal the batch-1 gradients; an all-ignored label
+    set of one sample contributes nothing."""
+    import torch.nn.functional as F
+    ops = _ops()
+    b, l, v = 5, 9, 30522
+    r = np.random.RandomState(7)
+    logits = torch.from_numpy(r.standard_normal((b, l, v)).astype(np.float32))
+    labels = torch.full((b, k, l), -100, dtype=torch.long)
+    for s in range(b):
+        for j in range(k):
+            if j > 0 and s % 2 == 0:
+                continue                       # ragged K: this sample has fewer label sets
+            n_valid = 1 + (s + j) % 3
+            pos = r.choice(np.arange(1, l), n_valid, replace=False)
+            labels[s, j, pos] = torch.from_numpy(r.randint(0, v, n_valid))
+    lg = logits.clone().requires_grad_(True)
+    want = 0.0
+    for s in range(b):
+        for j in range(k):
+            if (labels[s, j] != -100).any():
+                want = want + F.cross_entropy(lg[s], labels[s, j], ignore_index=-100)
+    want.backward()
+    sets = labels.permute(1, 0, 2).reshape(k, -1).to(DEV)
+    slot = torch.zeros(1, device=DEV)
+    g = ops.mlm_cross_entropy(logits.to(DEV), sets, slot, accumulate=False, rows_per_sample=l)
+    assert torch.allclose(slot.cpu()[0], want.detach(), rtol=1e-4)
+    assert torch.allclose(g.cpu(), lg.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_greedy_accept_on_device_equals_host_loop():
+    """vqa_greedy_accept (one wave per sample, device-resident ids) vs the host acceptance loop with the same
+    bag-of-embeddings similarity, random candidates incl. ties, repeated positions, padding and empty samples."""
+    from vqattack_amd.attack import text_update
+    ops = _ops()
+    r = np.random.RandomState(3)
+    b, l, v, e = 37, 23, 500, 64
+    table = r.standard_normal((v, e)).astype(np.float32)
+    ori = r.randint(1, v, size=(b, l)).astype(np.int64)
+    for s in range(b):
+        ori[s, 4 + s % (l - 4):] = 0
+    cur = ori.copy()
+    cur[:, 2] = r.randint(1, v, size=b)                     # already one substitution behind
+    proposals = []
+    for s in range(b):
+        per = [] if s % 9 == 0 else [(int(p), [int(x) for x in r.randint(1, v, 5)])
+                                      for p in r.choice(np.arange(1, 4 + s % (l - 4)), min(3, 3 + s % (l - 4)), replace=False)]
+        proposals.append(per)
+    plan = text_update.CandidatePlan(proposals, DEV)
+    scores = r.standard_normal(len(plan)).astype(np.float32)
+    scores[::7] = scores[1::7][:len(scores[::7])] if len(scores) > 8 else scores[::7]     # ties
+    sim = text_update.BagOfEmbeddingsSimilarity(table=table)
+    for thr in (0.95, 0.5, -1.0):
+        want_ids, want_ops = text_update.greedy_accept(plan.rows, scores, ori, cur, sim, thr)
+        got = torch.from_numpy(cur).to(DEV)
+        prev = got.clone()
+        new_id, rank = ops.greedy_accept(plan.device_rows, torch.from_numpy(scores).to(DEV),
+                                         torch.from_numpy(ori).to(DEV), got, sim.device_table(DEV), thr)
+        assert np.array_equal(got.cpu().numpy(), want_ids), thr
+        assert text_update.substitution_lists(prev, new_id, rank) == want_ops
+    assert any(len(o) for o in want_ops)

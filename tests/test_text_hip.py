@@ -1,0 +1,218 @@
+"""The SHIPPED text path on the MI355X (HIP kernels through the C ABI + the batched driver) against the vectors
+produced by executing the reference's own methods (``tests/golden/text_golden.*``, see make_text_golden.py):
+masked-token embedding substitution (``vqa_embed_tokens``), candidate scoring (``vqa_cand_dir_sim``), acceptance on the
+device (``vqa_greedy_accept``) and on the host, the whole per-sample attack loops of both flavors (feature and dual
+loss) and the black-box scorers.
+
+Tolerances (fp32): embeddings 2e-5 relative (LayerNorm reduction order differs from ATen's); token ids, schedules and
+accepted substitutions must be EQUAL; adversarial images >= 99.5 % of the pixels bit-identical and the rest within
+2 * eps_iter * steps (sign-PGD: a last-bit difference in an activation can flip isolated pixels); loss lists 2e-4.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import textworld as tw
+from tests.test_text_golden_loops import build_model, vlmo_tiny40  # noqa: F401  (model factories + checksum guard)
+from vqattack_amd import ops
+from vqattack_amd.attack import mlm_task, text_update
+from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = np.load(os.path.join(HERE, "golden", "text_golden.npz"))
+    with open(os.path.join(HERE, "golden", "text_golden.json")) as fh:
+        meta = json.load(fh)
+    return z, meta
+
+
+def device_tables(z, dim):
+    t = {k: torch.from_numpy(z["tab{}_{}".format(dim, k)]).to(DEV) for k in ("word", "pos", "type_emb", "gamma", "beta")}
+    t["ln_eps"] = 1e-12
+    return t
+
+
+def banned_mask(meta):
+    fw = set(meta["filter_in_vocab"])
+    return torch.tensor([("##" in tok) or (tok in fw) for tok in meta["vocab"]])
+
+
+@pytest.mark.parametrize("dim", [64, 768])
+def test_embed_tokens_equals_reference_bert_embeddings(gold, dim):
+    z, _ = gold
+    ids = torch.from_numpy(z["emb_ids_{}".format(dim)]).to(DEV)
+    got = ops.embed_tokens(device_tables(z, dim), ids).cpu().numpy()
+    np.testing.assert_allclose(got, z["emb_out_{}".format(dim)], rtol=2e-5, atol=2e-6)
+    # masked-token substitution: rewrite two rows in place after changing their ids
+    ids2 = ids.clone()
+    ids2[0, 4], ids2[2, 7] = 150, 160
+    out = torch.from_numpy(z["emb_out_{}".format(dim)]).to(DEV).clone()
+    ops.embed_tokens(device_tables(z, dim), ids2, out=out, rows=[(0, 4), (2, 7)])
+    full = ops.embed_tokens(device_tables(z, dim), ids2)
+    assert torch.equal(out[0, 4], full[0, 4]) and torch.equal(out[2, 7], full[2, 7])
+    keep = torch.ones(ids.shape, dtype=torch.bool, device=DEV)
+    keep[0, 4] = keep[2, 7] = False
+    assert torch.equal(out[keep], torch.from_numpy(z["emb_out_{}".format(dim)]).to(DEV)[keep])
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_scoring_and_acceptance_equal_reference_update_adv_text(gold, where):
+    """vqa_cand_dir_sim + (vqa_greedy_accept | host greedy_accept) vs update_adv_text (adv_attack.py:265-324)."""
+    z, meta = gold
+    tabs = device_tables(z, 64)
+    enc = tw.SentenceEncoderStandIn(None, z["use_table"])
+    sim = text_update.BagOfEmbeddingsSimilarity(table=z["use_table"]) if where == "device" else enc.similarity_ids
+    n_ops = 0
+    for c in meta["upd_cases"]:
+        ori = torch.tensor([c["ori_ids"]], device=DEV)
+        e_ori = ops.embed_tokens(tabs, ori)
+        proposals = [[(p, c["cand_ids"][w]) for w, p in zip(c["sub_list"], c["attack_vector"])]]
+        plan = text_update.CandidatePlan(proposals, DEV)
+        for r in c["rounds"]:
+            grad = torch.zeros(1, ori.shape[1], 64, device=DEV)
+            rows = torch.from_numpy(z[r["key"] + "_grad"]).to(DEV)
+            for k, p in enumerate(c["attack_vector"]):
+                grad[0, p] = rows[0, k]
+            cur = torch.tensor([r["cur_ids"]], device=DEV)
+            scores = text_update.score_plan(tabs, e_ori, grad, plan)
+            prev = cur.clone()
+            new_id, rank = text_update.accept_round(plan, scores, ori, cur, sim)
+            assert cur[0].tolist() == r["new_ids"], (where, c["flavor"], r["adv_text_in"])
+            subs = text_update.substitution_lists(prev, new_id, rank)[0]
+            assert [[old, new] for (_, old, new) in subs] == r["op_ids"]
+            n_ops += len(subs)
+    assert n_ops >= 4
+
+
+def _case_inputs(z, meta, flavor, c, model):
+    info = c["info"]
+    sub = [t for w in info["word_ids"] for t in w]
+    mlm_in = [tw.CLS] + sub + [tw.SEP]
+    logits = torch.from_numpy(tw.MlmStandIn(z["mlm_table"], z["mlm_drift"]).logits_for(mlm_in)).unsqueeze(0)
+    words = text_update.substitutable_words(info["keys"], info["word_filtered"])
+    ids = torch.tensor([c["text_ids"]])
+    attackable = torch.zeros_like(ids, dtype=torch.bool)
+    for w in words:
+        attackable[0, info["keys"][w][0] + 1] = True
+    att_mlm = attackable[:, :len(mlm_in)]
+    # the schedule counts every substitutable word (count, :224-231); only those with candidates are probed (:577-580)
+    proposals = text_update.propose_candidates(logits, torch.tensor([mlm_in]), att_mlm, banned=banned_mask(meta))
+    t = c["task"]
+    tup = lambda ws: [tuple(w) for w in ws]      # noqa: E731
+    task = mlm_task.build_mlm_task(tup(t["ans_word_ids"]), [tup(a) for a in t["all_ans_word_ids"]], t["same_as_vilt"],
+                                   tup(t["pa_word_ids"]), tup(t["stop_word_ids"]), flavor,
+                                   tail=() if flavor == "albef" else (t["period_id"],))
+    masks = torch.tensor([c["text_masks"]]) if "text_masks" in c else torch.ones_like(ids)
+    return proposals, attackable, task, ids, masks
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("flavor", ["albef", "vlmo"])
+def test_batched_driver_equals_reference_loop(gold, flavor, where):
+    """BatchedVQAttack.attack_batch (HIP operators, batched adapters, device or host acceptance) vs the reference's own
+    per-sample loop code run over the same tiny white box (adv_attack.py:428-712; vlmo_module.py:1743-2057)."""
+    z, meta = gold
+    model = build_model(flavor, meta).to(DEV)
+    if flavor == "albef":
+        from vqattack_amd.whitebox.albef import AlbefAttackAdapters as Adapters
+    else:
+        from vqattack_amd.whitebox.vlmo import VlmoAttackAdapters as Adapters
+    enc = tw.SentenceEncoderStandIn(None, z["use_table"])
+    sim = text_update.BagOfEmbeddingsSimilarity(table=z["use_table"]) if where == "device" else enc.similarity_ids
+    attack = BatchedVQAttack(Adapters(model), flavor, model.embedding_tables(), AttackConfig(sanity_checks=True),
+                             similarity_fn=sim)
+    for c in meta["loop_" + flavor]["cases"]:
+        proposals, attackable, task, ids, masks = _case_inputs(z, meta, flavor, c, model)
+        assert task.old_alg == c["old_alg"]
+        image = torch.from_numpy(z[c["key"] + "_image"]).to(DEV)
+        eta = torch.from_numpy(z[c["key"] + "_eta"]).to(DEV)
+        dual = task.old_alg == 0
+        res = attack.attack_batch(image, ids.to(DEV), masks.to(DEV), attackable.to(DEV), proposals=proposals,
+                                  init_eta=eta, dual=dual, tasks=[task] if dual else None)
+        assert res.adv_text_ids[0].tolist() == c["adv_text_ids"], (c["name"], c["adv_text"])
+        assert res.gradient_steps == 40 + int(attackable.sum())
+        assert len(res.loss_lists) == len(c["pgd_calls"])
+        for got, want in zip(res.loss_lists, c["pgd_calls"]):
+            np.testing.assert_allclose(got, want["losses"], rtol=2e-4, atol=2e-5)
+        want_adv = torch.from_numpy(z[c["key"] + "_adv"])
+        got_adv = res.adv_images.cpu()
+        same = float((got_adv == want_adv).float().mean())
+        assert same >= 0.995, (c["name"], same)
+        assert float((got_adv - want_adv).abs().max()) <= 2 * 0.01 * res.gradient_steps + 1e-6
+
+
+def test_batched_rank_answer_equals_reference_method(gold):
+    """FrozenAlbef.rank_answer / vqa_answer (batched, no per-question loop) vs ALBEF.rank_answer (model_vqa.py:149-203)
+    and the prediction read-out of adv_attack.py:722-726."""
+    from vqattack_amd.whitebox.albef import FrozenAlbef, albef_tiny
+    z, meta = gold
+    cfg = albef_tiny(mlm_probability=0.0)
+    black = FrozenAlbef.finetuned_from(FrozenAlbef(cfg, seed=3), seed=4).to(DEV)
+    images = torch.from_numpy(z["rank_images"]).to(DEV)
+    ids = torch.tensor(meta["rank"]["text_ids"], device=DEV)
+    masks = (ids != 0).long()
+    with torch.no_grad():
+        image_states, _ = black.visual_encoder(images)
+        states, _ = black.text_encoder(black.text_embeddings(ids), masks, image_states)
+        topk_ids, topk_probs = black.rank_answer(states, masks)
+    np.testing.assert_allclose(topk_probs.cpu().numpy(), z["rank_topk_probs"], rtol=2e-4, atol=1e-6)
+    assert torch.equal(topk_ids.cpu(), torch.from_numpy(z["rank_topk_ids"]))
+    assert black.vqa_answer(images, ids, masks).tolist() == meta["rank"]["pred"]
+
+
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_black_box_answers_equal_per_question_oracle(size):
+    """Batched black-box scorers vs the per-question CPU oracle (oracle/blackbox_ref.py) on seeded samples: the answer
+    indices that decide every attack-success bit must agree (32 samples tiny, one batch at base size)."""
+    from oracle import blackbox_ref as bb
+    from vqattack_amd.whitebox.albef import FrozenAlbef, albef_base, albef_tiny
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, vlmo_base, vlmo_tiny
+    n = 32 if size == "tiny" else 4
+    g = torch.Generator().manual_seed(5)
+    # ALBEF victim: rank_answer
+    cfg = albef_tiny(mlm_probability=0.0) if size == "tiny" else albef_base(image_size=224, mlm_probability=0.0)
+    black = FrozenAlbef.finetuned_from(FrozenAlbef(cfg, seed=1), seed=2)
+    images = torch.empty(n, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    ids = torch.zeros(n, 12, dtype=torch.long)
+    for b in range(n):
+        k = 3 + b % 7
+        ids[b, 0], ids[b, 1 + k] = 101, 102
+        ids[b, 1:1 + k] = torch.randint(1000, 30522, (k,), generator=g)
+    masks = (ids != 0).long()
+    want = []
+    with torch.no_grad():
+        for b in range(n):                               # one question at a time, like the reference's loop
+            st, _ = black.visual_encoder(images[b:b + 1])
+            q, _ = black.text_encoder(black.text_embeddings(ids[b:b + 1]), masks[b:b + 1], st)
+            ans = black.answer_ids
+            ti, tp = bb.rank_answer(black._decode, q, masks[b:b + 1], ans, (ans != cfg.pad_id).long(),
+                                    min(cfg.k_test, cfg.n_answers), pad_id=cfg.pad_id)
+            want += bb.albef_predict(ti, tp)
+    got = black.to(DEV).vqa_answer(images.to(DEV), ids.to(DEV), masks.to(DEV)).tolist()
+    assert got == want
+    del black
+    # VLMo victim: answer classifier
+    vcfg = vlmo_tiny() if size == "tiny" else vlmo_base(image_size=224)
+    vblack = FrozenVlmo.finetuned_from(FrozenVlmo(vcfg, seed=1), seed=2)
+    vimages = torch.empty(n, 3, vcfg.image_size, vcfg.image_size).uniform_(-1, 1, generator=g)
+    vids = torch.zeros(n, vcfg.max_text_len, dtype=torch.long)
+    for b in range(n):
+        k = 2 + b % (vcfg.max_text_len - 3)
+        vids[b, 0], vids[b, 1 + k] = 101, 102
+        vids[b, 1:1 + k] = torch.randint(1000, 30522, (k,), generator=g)
+    vmasks = (vids != 0).long()
+    with torch.no_grad():
+        vwant = []
+        for b in range(n):
+            _, states = vblack.encode(vimages[b:b + 1], vblack.text_embeddings(vids[b:b + 1]), vmasks[b:b + 1])
+            vwant += bb.vlmo_predict(vblack.vqa_classifier(vblack.pooled(states)))
+    vgot = vblack.to(DEV).vqa_answer(vimages.to(DEV), vids.to(DEV), vmasks.to(DEV)).tolist()
+    assert vgot == vwant

@@ -52,11 +52,12 @@ SIGNATURES = {
     "vqa_neg_cos_rows_multi": (_i, [_p, _p, _p, _i, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p, _i, _p]),
     "vqa_sum_partials": (_i, [_p, _i, _p, _i, _f, _p]),
     "vqa_ce_max_label_sets": (_i, []),
-    "vqa_ce_scratch_floats": (_i, []),
-    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _p, _p, _p, _f, _p, _i, _p, _p]),
+    "vqa_ce_scratch_floats": (_l, [_i, _l]),
+    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _l, _p, _p, _p, _f, _p, _i, _p, _p]),
     "vqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_embed_tokens": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
+    "vqa_greedy_accept": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "vqa_resize_bicubic_h_u8": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "vqa_resize_bicubic_v_normalize": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p]),
 }

@@ -23,7 +23,7 @@ import torch
 
 from .. import attacks, dropin, layout, ops
 from ..features import LayerFeatures
-from . import text_update
+from . import mlm_task, text_update
 from .schedule import IMAGE_STEP_BUDGET, iter_schedule
 
 
@@ -47,8 +47,30 @@ class BatchResult:
     adv_images: torch.Tensor
     adv_text_ids: torch.Tensor
     loss_lists: list = field(default_factory=list)
-    substitutions: list = field(default_factory=list)
+    substitutions: list = field(default_factory=list)   # per round: per sample [(position, old id, new id), ...]
     gradient_steps: int = 0
+    adv_text_ids_mlm: torch.Tensor = None               # dual-loss samples: the [MASK]-ed paraphrase after the attack
+
+
+def stack_mlm_tasks(tasks, device, dtype=torch.int64):
+    """(ids (B, Lm), mask (B, Lm), labels (B, Lm) or (B, K, Lm)) of a batch of ``mlm_task.MlmTask`` with old_alg == 0.
+    Samples are padded to the longest paraphrase (pad id 0, mask 0, label -100) and to the largest number of label sets
+    (an all-ignored set adds nothing to a sample's loss or gradient)."""
+    lm = max(len(t.text_ids_mlm) for t in tasks)
+    sets = [t.mlm_labels if isinstance(t.mlm_labels[0], list) else [t.mlm_labels] for t in tasks]
+    k = max(len(x) for x in sets)
+    ids = torch.zeros(len(tasks), lm, dtype=dtype)
+    mask = torch.zeros(len(tasks), lm, dtype=dtype)
+    labels = torch.full((len(tasks), k, lm), mlm_task.IGNORE, dtype=torch.int64)
+    for b, (t, ls) in enumerate(zip(tasks, sets)):
+        n = len(t.text_ids_mlm)
+        ids[b, :n] = torch.tensor(t.text_ids_mlm)
+        mask[b, :n] = torch.tensor(t.text_mask_mlm)
+        for j, row in enumerate(ls):
+            labels[b, j, :len(row)] = torch.tensor(row)
+    if k == 1:
+        labels = labels[:, 0]
+    return ids.to(device), mask.to(device), labels.to(device)
 
 
 class BatchedVQAttack:
@@ -83,11 +105,11 @@ class BatchedVQAttack:
             return self.pgd(a.pgd_attack, adv, c.eps, c.eps_iter, steps, c.norm, y=self._y_feature(targets), ls=1,
                             graph=c.use_graph and steps > 2, **common)
         return self.pgd([a.pgd_attack, a.pgd_mlm_attack], adv, c.eps, c.eps_iter, steps // 2, c.norm,
-                        y=self._y_dual(targets, mlm_labels), ls=0, **common)
+                        y=self._y_dual(targets, mlm_labels), ls=0, per_sample=True, **common)
 
     @torch.no_grad()
     def attack_batch(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, dual=False,
-                     mlm_labels=None, init_eta=None, proposals=None, text_ids_mlm=None):
+                     mlm_labels=None, init_eta=None, proposals=None, text_ids_mlm=None, text_mask_mlm=None, tasks=None):
         """Attack one batch whose samples all have the same number of attackable words.
 
         images (B,3,H,W) in [clip_min, clip_max]; text_ids/text_masks (B,L); attackable bool (B,L) with the same
@@ -96,25 +118,43 @@ class BatchedVQAttack:
         ``proposals`` injects them directly (``text_update.propose_candidates`` format).  Returns a ``BatchResult``.
 
         ``dual=True`` runs the reference's ``old_alg == 0`` blocks (feature step + MLM step per iteration,
-        adv_attack.py:614-619,670-676) with ``mlm_labels`` (B, L) / (B, K, L); ``text_ids_mlm`` is the [MASK]-ed
-        paraphrase the MLM closure reads (``self.batch["text_ids_mlm"]``), kept position-aligned with the question:
-        accepted substitutions are applied to it too, like ``update_mlm_text`` (:334-351).
+        adv_attack.py:614-619,670-676).  The MLM side is given either as ``tasks`` -- one ``mlm_task.MlmTask`` per sample
+        (``mlm_task.build_mlm_task``): ids, masks and labels are stacked from them and every accepted substitution is
+        applied to the paraphrase's word list like ``update_mlm_text`` (:334-351) -- or as ready tensors
+        ``mlm_labels`` (B, L) / (B, K, L), ``text_ids_mlm``, ``text_mask_mlm`` that stay fixed during the attack.
         """
         c, a = self.cfg, self.adapters
+        dev = images.device
         n_words = int(attackable[0].sum().item())
         if not bool((attackable.sum(dim=1) == n_words).all()):
             raise ValueError("samples of one batch must share a schedule: bucket them with bucket_by_schedule()")
         blocks = iter_schedule(n_words, c.budget)
         images, init_eta, restore = self._enter_layout(images, init_eta)
-        a.set_text(text_ids, text_masks)
-        targets = a.gen_ori_feats(images)
         adv = images
-        adv_ids = text_ids.clone()
-        mlm_ids = None if text_ids_mlm is None else text_ids_mlm.clone()
-        if mlm_ids is not None:
-            a.set_text(text_ids, text_masks, text_ids_mlm=mlm_ids)
+        adv_ids = text_ids.clone().contiguous()
+        mlm_ids = mlm_mask = None
+        if tasks is not None:
+            if not dual or any(t.old_alg != 0 for t in tasks):
+                raise ValueError("tasks= is for dual-loss batches: every MlmTask must have old_alg == 0")
+            tasks = [mlm_task.MlmTask(**vars(t)) for t in tasks]                 # private copies: word lists are edited
+            for t in tasks:
+                t.words_mlm = list(t.words_mlm)
+            mlm_ids, mlm_mask, mlm_labels = stack_mlm_tasks(tasks, dev, text_ids.dtype)
+        elif text_ids_mlm is not None:
+            mlm_ids = text_ids_mlm.clone()
+            mlm_mask = text_mask_mlm
+        # the text layout (trimmed padding) is fixed here for targets and every later step: question AND paraphrase masks
+        a.set_text(text_ids, text_masks, text_ids_mlm=mlm_ids, text_mask_mlm=mlm_mask)
+        # adapters that trim padding zero-pad the MLM logits back to the full text length (VlmoAttackAdapters): a label
+        # there would be scored against those zeros
+        tlen = getattr(a, "_tlen", None) if getattr(a, "trim_padding", False) else None
+        if dual and mlm_labels is not None and tlen is not None and tlen < mlm_labels.shape[-1] and \
+                bool((mlm_labels[..., tlen:] != mlm_task.IGNORE).any()):
+            raise ValueError("MLM labels beyond the batch's text length {} must be ignore_index".format(tlen))
+        targets = a.gen_ori_feats(images)
         res = BatchResult(adv_images=adv, adv_text_ids=adv_ids)
         first_time = 0 if c.random_start else 1
+        rounds = []
         if not blocks:
             with torch.enable_grad():
                 adv, losses = self._pgd_block(adv, images, targets, c.budget, first_time, dual, mlm_labels, init_eta)
@@ -126,14 +166,16 @@ class BatchedVQAttack:
                 if fn is not None:
                     proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
                                                                banned=self.banned_ids)
-            # text embeddings of the question batch: one launch; after every substitution round only the rows of the
-            # replaced words are rewritten (masked-token embedding substitution, ops.embed_tokens)
+            plan = None if proposals is None else text_update.CandidatePlan(proposals, dev)   # uploaded once
+            # text embeddings of the question batch: one launch; after every substitution round the batch is re-embedded
+            # from the device-resident ids (masked-token embedding substitution, ops.embed_tokens) -- the host never has
+            # to learn which words changed
             e_ori = ops.embed_tokens(self.tables, text_ids)
             adv_emb = e_ori.clone()
-            ori_host = text_ids.cpu().numpy()
+            ori_ids = text_ids.contiguous()
             positions = list(range(text_ids.shape[1]))
             for bi, steps in enumerate(blocks):
-                a.set_text(adv_ids, text_masks, text_ids_mlm=mlm_ids)
+                a.set_text(adv_ids, text_masks, text_ids_mlm=mlm_ids, text_mask_mlm=mlm_mask)
                 with torch.enable_grad():
                     adv, losses = self._pgd_block(adv, images, targets, steps, first_time if bi == 0 else 1, dual,
                                                   mlm_labels, init_eta if bi == 0 else None)
@@ -147,21 +189,22 @@ class BatchedVQAttack:
                                                  y=self._y_feature(targets), time=1, ori_x=images, ls=1,
                                                  attack_mask=positions, sanity_checks=c.sanity_checks)
                 res.gradient_steps += 1
-                if proposals is not None:
-                    cand, scores = text_update.score_candidates(self.tables, e_ori, text_grad, proposals)
-                    new_ids, subs = text_update.greedy_accept(cand, scores, ori_host, adv_ids.cpu().numpy(),
-                                                              self.similarity_fn, c.sim_threshold)
-                    adv_ids = torch.as_tensor(new_ids, device=text_ids.device, dtype=text_ids.dtype)
-                    res.substitutions.append(subs)
-                    changed = [(s, p) for s, per in enumerate(subs) for (p, _, _) in per]
-                    if changed:
-                        ops.embed_tokens(self.tables, adv_ids, out=adv_emb, rows=changed)
-                        if mlm_ids is not None:      # update_mlm_text: same word replaced in the MLM paraphrase
-                            for s, per in enumerate(subs):
-                                for (p, old, new) in per:
-                                    if int(mlm_ids[s, p]) == old:
-                                        mlm_ids[s, p] = new
-        res.adv_images, res.adv_text_ids = restore(adv), adv_ids
+                if plan is not None:
+                    scores = text_update.score_plan(self.tables, e_ori, text_grad, plan)
+                    prev = adv_ids.clone()
+                    new_id, rank = text_update.accept_round(plan, scores, ori_ids, adv_ids, self.similarity_fn,
+                                                            c.sim_threshold)            # adv_ids updated in place
+                    rounds.append((prev, new_id, rank))
+                    ops.embed_tokens(self.tables, adv_ids, out=adv_emb)
+                    if tasks is not None:        # update_mlm_text: the paraphrase follows the question's substitutions
+                        subs = text_update.substitution_lists(prev, new_id, rank)
+                        for s, per in enumerate(subs):
+                            if per:
+                                mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in per])
+                                ids_s = tasks[s].reencode()
+                                mlm_ids[s, :len(ids_s)] = torch.tensor(ids_s, device=dev, dtype=mlm_ids.dtype)
+        res.substitutions = [text_update.substitution_lists(*r) for r in rounds]     # one host read, after the attack
+        res.adv_images, res.adv_text_ids, res.adv_text_ids_mlm = restore(adv), adv_ids, mlm_ids
         return res
 
     def _enter_layout(self, images, init_eta):
@@ -216,13 +259,15 @@ class BatchedVQAttack:
                                                        banned=self.banned_ids) if fn is not None else [[] for _ in range(b)]
         else:
             proposals = [proposals[s] for s in order]
+        plan = text_update.CandidatePlan(proposals, dev)
         a.set_text(text_ids, text_masks)
         pinned = getattr(a, "_tlen", None)                                # token layout of the targets
         targets = a.gen_ori_feats(images)
         e_ori = ops.embed_tokens(self.tables, text_ids)
         adv_emb = e_ori.clone()
-        adv_ids = text_ids.clone()
-        ori_host = text_ids.cpu().numpy()
+        adv_ids = text_ids.clone().contiguous()
+        ori_ids = text_ids.contiguous()
+        rounds = []
         flag = ops.new_flag(dev)
         eta = init_eta
         if eta is None and c.random_start:
@@ -247,18 +292,17 @@ class BatchedVQAttack:
                           out=cur[:n_act])                                # in place: finished samples stay untouched
             firing = [s for s in range(n_act) if t in probes[s]]
             if firing:
-                props = [proposals[s] if s in firing else [] for s in range(n_act)]
-                cand, scores = text_update.score_candidates(self.tables, e_ori[:n_act], leaf_txt.grad, props)
-                new_ids, subs = text_update.greedy_accept(cand, scores, ori_host[:n_act], adv_ids[:n_act].cpu().numpy(),
-                                                          self.similarity_fn, c.sim_threshold)
-                changed = [(s, p) for s, per in enumerate(subs) for (p, _, _) in per]
-                if changed:
-                    adv_ids[:n_act] = torch.as_tensor(new_ids, device=dev, dtype=adv_ids.dtype)
-                    ops.embed_tokens(self.tables, adv_ids, out=adv_emb, rows=changed)
-                    a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
-                res.substitutions.append(subs)
+                sub = plan.restricted_to(firing)
+                scores = text_update.score_plan(self.tables, e_ori[:n_act], leaf_txt.grad, sub)
+                prev = adv_ids[:n_act].clone()
+                new_id, rank = text_update.accept_round(sub, scores, ori_ids[:n_act], adv_ids[:n_act],
+                                                        self.similarity_fn, c.sim_threshold)   # in place, on the device
+                rounds.append((prev, new_id, rank))
+                ops.embed_tokens(self.tables, adv_ids, out=adv_emb)
+                a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
         if c.sanity_checks:
             assert int(flag.item()) == 0, "input images are outside [clip_min, clip_max]"
+        res.substitutions = [text_update.substitution_lists(*r) for r in rounds]
         res.adv_images, res.adv_text_ids = restore(cur[inv]), adv_ids[inv]
         res.loss_lists = [losses.tolist()]
         res.gradient_steps = sum(total)

@@ -16,25 +16,28 @@ from .runner import AttackConfig, BatchedVQAttack
 from .schedule import bucket_by_schedule, gradient_steps
 
 
-MASK_ID = 103
+def synthetic_mlm_tasks(ids, dual_every, flavor, seed=0, max_len=None):
+    """Synthetic stand-in for the per-question side data of the reference (victim answer, correct-answer list,
+    declarative paraphrase: ``vilt_ans_table``, ``all_correct_ans``, ``chatgpt`` tables, adv_attack.py:62-79), fed through
+    the real decision logic ``mlm_task.build_mlm_task`` (adv_attack.py:433-558).
 
-
-def synthetic_mlm_task(ids, att, dual_every, seed=0):
-    """Synthetic stand-in for the reference's ``old_alg == 0`` samples (adv_attack.py:433-558: the declarative
-    paraphrase with the answer word [MASK]-ed): every ``dual_every``-th question gets its first body token masked in
-    the MLM text and that token as the only label.  Returns (dual bool (n,), ids_mlm (n, L), labels (n, L))."""
-    n = ids.shape[0]
-    dual = torch.zeros(n, dtype=torch.bool)
-    if dual_every:
-        dual[::dual_every] = True
-    ids_mlm = ids.clone()
-    labels = torch.full_like(ids, -100)
-    for s in torch.nonzero(dual).flatten().tolist():
-        p = 1                                     # first body token ([CLS] is position 0)
-        labels[s, p] = ids[s, p]
-        ids_mlm[s, p] = MASK_ID
-        att[s, p] = False                         # the answer word is not a substitution target
-    return dual, ids_mlm, labels
+    Paraphrase of sample s = its question words followed by one answer word.  Every ``dual_every``-th sample's victim
+    answer IS that word (-> old_alg = 0: the word is [MASK]-ed and becomes the MLM label; every third of those has a
+    second correct answer of the same piece count -> 3-d labels); the other samples' victim answer does not occur in
+    the paraphrase (-> old_alg = 1, feature loss only).  Returns one ``MlmTask`` per sample."""
+    from . import mlm_task
+    r = np.random.RandomState(seed + 1)
+    tasks = []
+    for s in range(ids.shape[0]):
+        body = [(int(t),) for t in ids[s].tolist() if t not in (0, 101, 102)]
+        in_para, other, alt = (int(v) for v in r.randint(1000, 30522, 3))
+        para = body + [(in_para,)]
+        is_dual = bool(dual_every) and s % dual_every == 0
+        answer = [(in_para,)] if is_dual else [(other,)]
+        correct = [answer, [(alt,)]] if (is_dual and (s // dual_every) % 3 == 0) else [answer]
+        tasks.append(mlm_task.build_mlm_task(answer, correct, [True] + [False] * (len(correct) - 1), para, [], flavor,
+                                             max_len=max_len))
+    return tasks
 
 
 def synthetic_questions(n_samples, text_len, seed=0, min_words=4, max_words=12, joint=True):
@@ -62,16 +65,22 @@ def synthetic_images(qids, image_size, device):
 
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
-              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False):
+              config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False,
+              attack=None):
     """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank.
+    ``attack``: a ready ``BatchedVQAttack`` (or an object with its ``attack_batch`` / ``attack_mixed`` / ``cfg``) instead
+    of one built from ``adapters`` -- the multi-rank CPU tests inject a stand-in to exercise shard -> ledger -> gather.
 
     ``mixed=False``: samples are bucketed by (schedule, loss mode) and every batch is schedule-pure
     (``BatchedVQAttack.attack_batch``).  ``mixed=True``: feature-loss samples are batched in index order whatever their
     word counts (``attack_mixed``, prefix scheduling); dual-loss samples still go through their buckets."""
     ids, masks, att = synthetic_questions(n_samples, text_len, seed=seed, joint=joint, max_words=max_words)
-    dual, ids_mlm, mlm_labels = synthetic_mlm_task(ids, att, dual_every, seed=seed)
+    tasks = synthetic_mlm_tasks(ids, dual_every, flavor, seed=seed, max_len=text_len if flavor == "vlmo" else None)
+    dual = torch.tensor([t.old_alg == 0 for t in tasks])
     mine = shard_indices(n_samples, rank, world)
-    attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
+    device = torch.device(device)
+    if attack is None:
+        attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
     ledger = SuccessLedger(world, rank, device)
     # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg;
     # with mixed=True all feature-loss samples share ONE bucket (key -2) and are scheduled per sample inside the batch
@@ -95,8 +104,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             if key == -2:
                 res = attack.attack_mixed(images, tid, tmask, tatt)
             elif is_dual:
-                res = attack.attack_batch(images, tid, tmask, tatt, dual=True, mlm_labels=mlm_labels[qids].to(device),
-                                          text_ids_mlm=ids_mlm[qids].to(device))
+                res = attack.attack_batch(images, tid, tmask, tatt, dual=True, tasks=[tasks[q] for q in qids])
             else:
                 res = attack.attack_batch(images, tid, tmask, tatt)
             after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
@@ -115,7 +123,8 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
                       flush=True)
     if writer is not None:
         writer.close()
-    torch.cuda.synchronize(device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     asr = ledger.all_gather_rate()
     return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,

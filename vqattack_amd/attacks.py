@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from ._hip import HipExtensionError
-from .features import layer_pairs
+from .features import LayerFeatures, layer_pairs
 
 ALBEF = "albef"
 VLMO = "vlmo"
@@ -169,19 +169,23 @@ def _label_sets(labels):
     raise ValueError("MLM labels must be 2-d or 3-d")
 
 
-def _ce_backward(logits, label_sets, slot, leaves, sign, scale=1.0, accumulate=False, flag=None, ws=None):
-    """Fused cross entropy: loss into ``slot``; returns ``(tensors, grads)`` for the autograd sweep (one HIP launch)."""
+def _ce_backward(logits, label_sets, slot, leaves, sign, scale=1.0, accumulate=False, flag=None, ws=None,
+                 per_sample=False):
+    """Fused cross entropy: loss into ``slot``; returns ``(tensors, grads)`` for the autograd sweep (one HIP launch).
+    ``per_sample``: normalise every label set by each SAMPLE's own valid-label count (batched drivers: per-sample
+    gradients then equal the batch-1 reference's) instead of ``F.cross_entropy``'s mean over the whole batch."""
+    rows_per_sample = logits.shape[1] if (per_sample and logits.dim() == 3) else 0
     if logits.shape[-1] != MLM_VOCAB:
         logits = logits.reshape(-1, MLM_VOCAB)          # the reference's .view(-1, 30522)
     l32 = logits if logits.dtype == torch.float32 else logits.to(torch.float32)
     needs_grad = l32.requires_grad
     g = ops.mlm_cross_entropy(l32.detach(), label_sets, slot.word, accumulate=accumulate, gscale=sign * scale,
-                              want_grad=needs_grad, flag=flag, ws=ws)
+                              want_grad=needs_grad, flag=flag, ws=ws, rows_per_sample=rows_per_sample)
     return ([l32], [g]) if needs_grad else ([], [])
 
 
 def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bkp=None, bkp_y=None, vl=False,
-                   ws=None, flag=None):
+                   ws=None, flag=None, per_sample=False):
     """Run the white box, evaluate the selected loss into ``slot`` and leave d loss/d leaf in ``leaf.grad``.
     ``ws`` (``ops.Workspace``): gradient / scratch buffers reused across the iterations of one attack call;
     ``flag``: the attack's int32 device word (bad MLM labels are reported there, see ``ops.mlm_cross_entropy``)."""
@@ -193,7 +197,8 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             if ls == 1:
                 _feature_loss_backward(pairs, slot, leaves, sign, ws=ws)
             elif ls == 0:
-                t, g = _ce_backward(out[0], y[0].reshape(1, -1), slot, leaves, sign, flag=flag, ws=ws)
+                t, g = _ce_backward(out[0], y[0].reshape(1, -1), slot, leaves, sign, flag=flag, ws=ws,
+                                    per_sample=per_sample)
                 torch.autograd.backward(t, g, inputs=leaves)
             else:
                 raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
@@ -213,13 +218,18 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
         if ls == 1:
             _feature_loss_backward(_feature_pairs(out, y, flavor, vl=False), slot, leaves, sign, ws=ws)
         elif ls == 0:
-            t, g = _ce_backward(out[0], _label_sets(y[0]), slot, leaves, sign, flag=flag, ws=ws)
+            t, g = _ce_backward(out[0], _label_sets(y[0]), slot, leaves, sign, flag=flag, ws=ws, per_sample=per_sample)
             if not t:
                 raise RuntimeError("model_fn's logits do not depend on the attacked input")
             torch.autograd.backward(t, g, inputs=leaves)
         elif flavor == VLMO:
             # mixed loss, V: fast_gradient_method.py:127-131 (no truncation in this branch): feature loss / (13*Ntok)
             # + 0.1 * CE(labels) + 0.1 * sum over synonym label sets -- all CE terms in ONE fused launch
+            if isinstance(out[2], LayerFeatures) and out[2].layers[0].shape[0] > 1:
+                # the three terms are weighted per SAMPLE in the reference (batch 1: 1/(13*Ntok) with that sample's
+                # token count, CE means over that sample's labels); with several samples in one LayerFeatures batch the
+                # ratios would differ per sample and change sign(grad).  The reference's drivers never reach this branch.
+                raise ValueError("the VLMO mixed loss (ls not in {0, 1}) is defined for batch-1 model outputs only")
             sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
             scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
             pairs = [(out[2], y[2])] if out[1] is None else [(out[1], y[1]), (out[2], y[2])]
@@ -255,7 +265,7 @@ def _grad_of(leaf):
 
 # ----------------------------------------------------------------------------------------- FGM
 def fast_gradient_method(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=None, y=None, targeted=False,
-                         sanity_checks=False, ls=None, bkp=None, bkp_y=None, *, flavor=ALBEF):
+                         sanity_checks=False, ls=None, bkp=None, bkp_y=None, *, flavor=ALBEF, per_sample=False):
     """One FGM step; returns ``(adv_x, loss)`` (``loss`` is a 0-d device tensor), bare ``x`` when ``eps == 0``.
     Reference: A fast_gradient_method.py:30-165, V :36-152 (the VLMO copy has no ``bkp``/``bkp_y``)."""
     _check_flavor(flavor)
@@ -267,7 +277,7 @@ def fast_gradient_method(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=
     leaf = xin.detach().requires_grad_(True)           # shares storage with x: nothing is written in place
     loss_buf = torch.zeros(1, dtype=torch.float32, device=xin.device)
     _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, 0), bkp=bkp, bkp_y=bkp_y,
-                   flag=flag)
+                   flag=flag, per_sample=per_sample)
     _two_sided(clip_min, clip_max)
     adv = _fgm_update(xin, _grad_of(leaf), eps, norm, clip_min, clip_max, flag=flag)
     if sanity_checks and flag is not None:
@@ -365,12 +375,16 @@ def _graphed_linf_loop(model_fn, cur, x0, y, flavor, targeted, eps_iter, eps, cl
 
 def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_min=None, clip_max=None, y=None,
                                ori_x=None, time=None, targeted=False, rand_init=True, rand_minmax=None,
-                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None, graph=False):
+                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None, graph=False,
+                               per_sample=False):
     """PGD over a frozen white box; returns ``(adv_x, loss_list)``, bare ``x`` when eps or eps_iter is 0.
 
     ``ls == 1``: feature loss, ``model_fn`` a callable.  Otherwise the dual-loss loop: ``model_fn = [feature_fn,
     mlm_fn]``, one feature step then one MLM step per iteration with a single projection after both.
     ``init_eta`` (extension, keyword-only): the uniform draw to use when ``time == 0`` (for reproducible parity runs).
+    ``per_sample`` (extension, keyword-only): batched drivers set it so that the MLM cross entropy of the dual loop is
+    normalised per sample (every sample's gradient then equals the batch-1 reference's; the reported loss is the sum
+    of the per-sample losses instead of ``F.cross_entropy``'s batch mean).
     ``graph`` (extension, keyword-only): capture one iteration into a hipGraph and replay it (``ls == 1``, L-inf,
     two-sided or no clipping; for small, launch-bound batches -- see ``_graphed_linf_loop``).
     Reference: A projected_gradient_descent.py:10-199, V :10-196.
@@ -422,7 +436,7 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
             mid = _fgm_update(adv, _grad_of(leaf), eps_iter, norm, clip_min, clip_max, out=buf[1 - cur])
             leaf = mid.detach().requires_grad_(True)
             _loss_and_grad(model_fn[1], [leaf], leaf, y_mlm, 0, flavor, targeted, _LossSlot(loss_buf, n_loss), ws=ws,
-                           flag=bad_flag, **extra)
+                           flag=bad_flag, per_sample=per_sample, **extra)
             n_loss += 1
             adv = _fgm_then_project(mid, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[cur])
             cur = 1 - cur            # result sits in buf[cur] again after the flip below

@@ -25,26 +25,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWaves = kBlock / kWave;
 
 constexpr int kCeMaxK = 8;
-constexpr int kCeCounterSlot = kCeMaxK;       // scratch layout: K reciprocal counts, then the fold's arrival counters
-constexpr int kCeScratchFloats = kCeMaxK + kArriveWords;
+// scratch layout: the fold's arrival counters (kArriveWords), then K x groups reciprocal valid-label counts
 
-// inv_count[k] = 1 / #{r : labels[k][r] != ignore}   (F.cross_entropy's mean over non-ignored targets);
-// block 0 also zeroes the arrival counter of the in-kernel loss fold.
+// Normalisation of the mean: rows are split into `groups` consecutive groups of `rpg` rows (one group = one SAMPLE of
+// a batched attack; groups == 1 is F.cross_entropy's mean over the whole batch) and label set k of group g is divided
+// by its own number of non-ignored labels -- the batch-1 reference's loss, summed over the samples of the batch.
+struct CeNorm {
+  const float* inv_count;   // [K][groups]
+  long rpg, groups;
+};
+
+// inv_count[k][g] = 1 / #{r in group g : labels[k][r] != ignore}   (F.cross_entropy's mean over non-ignored targets);
+// block 0 also zeroes the arrival counters of the in-kernel loss fold.  One workgroup per (label set, group).
 __global__ __launch_bounds__(kBlock) void ce_count_kernel(const int64_t* __restrict__ labels, long rows,
-                                                          long ignore_index, float* __restrict__ inv_count) {
+                                                          long ignore_index, unsigned* __restrict__ counters,
+                                                          float* __restrict__ inv_count, long rpg, long groups) {
   __shared__ float lds[kWaves];
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < kArriveWords; i += kBlock) reinterpret_cast<unsigned*>(inv_count)[kCeCounterSlot + i] = 0u;
-  const int64_t* lab = labels + static_cast<long>(blockIdx.x) * rows;
+    for (int i = threadIdx.x; i < kArriveWords; i += kBlock) counters[i] = 0u;
+  const long k = blockIdx.x / groups, g = blockIdx.x - k * groups;
+  const int64_t* lab = labels + k * rows;
+  const long r1 = (g + 1) * rpg < rows ? (g + 1) * rpg : rows;
   float c = 0.0f;
-  for (long r = threadIdx.x; r < rows; r += kBlock) c += (lab[r] != ignore_index) ? 1.0f : 0.0f;
+  for (long r = g * rpg + threadIdx.x; r < r1; r += kBlock) c += (lab[r] != ignore_index) ? 1.0f : 0.0f;
   c = wave_sum(c);
   if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.0f;
     for (int w = 0; w < kWaves; ++w) s += lds[w];
-    inv_count[blockIdx.x] = 1.0f / s;     // all-ignored -> inf -> NaN loss, like torch's 0/0
+    inv_count[blockIdx.x] = 1.0f / s;     // all-ignored -> inf, never multiplied in: such a (set, group) adds 0
   }
 }
 
@@ -59,8 +69,7 @@ struct RowLabels {
 
 template <int MAXK>
 __device__ __forceinline__ RowLabels<MAXK> read_labels(const int64_t* __restrict__ labels, int K, long rows, long r,
-                                                       int V, long ignore_index,
-                                                       const float* __restrict__ inv_count,
+                                                       int V, long ignore_index, const CeNorm& norm,
                                                        const float* __restrict__ x, float lse) {
   RowLabels<MAXK> L;
   L.wsum = 0.0f;
@@ -75,7 +84,7 @@ __device__ __forceinline__ RowLabels<MAXK> read_labels(const int64_t* __restrict
       if (t != ignore_index) {
         if (t >= 0 && t < V) {
           L.lab[k] = t;
-          L.wk[k] = inv_count[k];
+          L.wk[k] = norm.inv_count[k * norm.groups + r / norm.rpg];
           L.wsum += L.wk[k];
           L.loss += L.wk[k] * (lse - x[t]);
         } else {
@@ -131,7 +140,7 @@ __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float
 template <bool GRAD, int MAXK>
 __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict__ logits, long row_stride,
                                                          const int64_t* __restrict__ labels, int K, long rows, int V,
-                                                         long ignore_index, const float* __restrict__ inv_count,
+                                                         long ignore_index, CeNorm norm,
                                                          float* __restrict__ grad, float* __restrict__ row_loss,
                                                          float gscale, int* __restrict__ flag) {
   __shared__ float lds_m[kWaves], lds_s[kWaves];
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
   for (int w = 1; w < kWaves; ++w)
     if (lds_m[w] != -INFINITY || m != -INFINITY) online_merge(m, s, lds_m[w], lds_s[w]);
   const float lse = m + logf(s);
-  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, inv_count, x, lse);
+  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, norm, x, lse);
   if (threadIdx.x == 0) {
     row_loss[r] = L.loss;
     if (L.bad && flag) atomicOr(flag, VQA_FLAG_BAD_LABEL);
@@ -239,7 +248,7 @@ __device__ __forceinline__ int edge_index(const RowGeom& g, int V) {
 template <bool GRAD, int MAXK, int THREADS, int WGPC>
 __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels, int K, long rows, int V, long ignore_index,
-    const float* __restrict__ inv_count, float* __restrict__ grad, float* __restrict__ row_loss, float gscale,
+    CeNorm norm, float* __restrict__ grad, float* __restrict__ row_loss, float gscale,
     int* __restrict__ flag, CeFold fold) {
   constexpr int kQuads = kRegFloats / 4 / THREADS;
   constexpr int kWavesT = THREADS / kWave;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
 #pragma unroll
   for (int w = 1; w < kWavesT; ++w) s += lds[w];
   const float lse = m + logf(s);
-  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, inv_count, cur.x, lse);
+  const RowLabels<MAXK> L = read_labels<MAXK>(labels, K, rows, r, V, ignore_index, norm, cur.x, lse);
   if (threadIdx.x == 0) {
     __hip_atomic_store(row_loss + r, L.loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (L.bad && flag) atomicOr(flag, VQA_FLAG_BAD_LABEL);
@@ -317,23 +326,23 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
 
 template <bool GRAD, int MAXK, int THREADS>
 static void launch_reg(int variant, long rows, hipStream_t st, const float* logits, const int64_t* labels, int K, int V,
-                       long ignore_index, const float* inv_count, float* grad, float* row_loss, float gscale,
+                       long ignore_index, const CeNorm& norm, float* grad, float* row_loss, float gscale,
                        int* flag, const CeFold& fold) {
   const int grid = static_cast<int>(rows);
   if (variant == 3 && THREADS == 256)     // 3 workgroups per CU: 168 VGPRs per lane, the 128-register row still fits
     ce_rows_reg_kernel<GRAD, MAXK, THREADS, (THREADS == 256 ? 3 : 2)><<<grid, THREADS, 0, st>>>(
-        logits, labels, K, rows, V, ignore_index, inv_count, grad, row_loss, gscale, flag, fold);
+        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
   else
     ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2><<<grid, THREADS, 0, st>>>(
-        logits, labels, K, rows, V, ignore_index, inv_count, grad, row_loss, gscale, flag, fold);
+        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
 }
 
 template <int THREADS>
 static void launch_reg_k(bool want_grad, int variant, long rows, hipStream_t st, const float* logits,
-                         const int64_t* labels, int K, int V, long ignore_index, const float* inv_count, float* grad,
+                         const int64_t* labels, int K, int V, long ignore_index, const CeNorm& norm, float* grad,
                          float* row_loss, float gscale, int* flag, const CeFold& fold) {
 #define VQA_CE_GO(G, MK) \
-  launch_reg<G, MK, THREADS>(variant, rows, st, logits, labels, K, V, ignore_index, inv_count, grad, row_loss, gscale, \
+  launch_reg<G, MK, THREADS>(variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, \
                              flag, fold)
   if (want_grad) {
     if (K == 1) VQA_CE_GO(true, 1); else if (K <= 4) VQA_CE_GO(true, 4); else VQA_CE_GO(true, 8);
@@ -351,7 +360,10 @@ extern "C" {
 
 int vqa_ce_max_label_sets(void) { return kCeMaxK; }
 
-int vqa_ce_scratch_floats(void) { return kCeScratchFloats; }
+long vqa_ce_scratch_floats(int K, long groups) {
+  if (K < 1 || groups < 1) return 0;
+  return kArriveWords + static_cast<long>(K) * groups;
+}
 
 int vqa_ce_set_threads(int threads) {   // reached through vqa_set_option(4, threads)
   if (threads != 256 && threads != 512 && threads != 1024) return VQA_ERR_SHAPE;
@@ -366,34 +378,42 @@ int vqa_ce_set_variant(int variant) {   // reached through vqa_set_option(5, var
 }
 
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
-                long ignore_index, float* scratch, float* grad, float* row_loss, float gscale, float* loss_out,
-                int accumulate, int* flag, vqa_stream_t stream) {
+                long ignore_index, long rows_per_group, float* scratch, float* grad, float* row_loss, float gscale,
+                float* loss_out, int accumulate, int* flag, vqa_stream_t stream) {
+  clear_stale_error();
   if (!logits || !labels || !scratch || !row_loss) return VQA_ERR_NULL;
-  if (K < 1 || K > kCeMaxK || rows < 0 || V <= 0 || row_stride < V) return VQA_ERR_SHAPE;
+  if (K < 1 || K > kCeMaxK || rows < 0 || V <= 0 || row_stride < V || rows_per_group < 0) return VQA_ERR_SHAPE;
+  const long rpg = (rows_per_group == 0 || rows_per_group > rows) ? (rows > 0 ? rows : 1) : rows_per_group;
+  const long groups = rows > 0 ? (rows + rpg - 1) / rpg : 1;
+  if (static_cast<long>(K) * groups > 0x7fffffffL) return VQA_ERR_SHAPE;
   if (!aligned4(logits) || (grad && !aligned4(grad)) || !aligned4(scratch)) return VQA_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (rows == 0) return loss_out ? vqa_sum_partials(row_loss, 0, loss_out, accumulate, gscale, stream) : VQA_OK;
-  ce_count_kernel<<<K, kBlock, 0, st>>>(labels, rows, ignore_index, scratch);
+  unsigned* counters = reinterpret_cast<unsigned*>(scratch);
+  float* inv_count = scratch + kArriveWords;
+  ce_count_kernel<<<static_cast<int>(K * groups), kBlock, 0, st>>>(labels, rows, ignore_index, counters, inv_count, rpg,
+                                                                   groups);
+  const CeNorm norm{inv_count, rpg, groups};
   // register path: row_stride == V keeps the gradient row's alignment phase equal to the logits row's
   const bool reg_path = V >= 8 && V <= kRegFloats - 8 && row_stride == V && aligned16(logits) && (!grad || aligned16(grad));
   if (reg_path) {
-    const CeFold fold{reinterpret_cast<unsigned*>(scratch) + kCeCounterSlot, loss_out, accumulate, gscale};
+    const CeFold fold{counters, loss_out, accumulate, gscale};
     const bool g = grad != nullptr;
     if (g_ce_threads == 256)
-      launch_reg_k<256>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
+      launch_reg_k<256>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
     else if (g_ce_threads == 512)
-      launch_reg_k<512>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
+      launch_reg_k<512>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
     else
-      launch_reg_k<1024>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, scratch, grad, row_loss, gscale, flag, fold);
+      launch_reg_k<1024>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
     return launch_status();
   }
   const int grid = static_cast<int>(rows);
   if (grad)
-    ce_rows_kernel<true, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, scratch,
+    ce_rows_kernel<true, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, norm,
                                                            grad, row_loss, gscale, flag);
   else
     ce_rows_kernel<false, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index,
-                                                            scratch, grad, row_loss, gscale, flag);
+                                                            norm, grad, row_loss, gscale, flag);
   const int rc = launch_status();
   if (rc != VQA_OK || !loss_out) return rc;
   if (rows > 0x7fffffffL) return VQA_ERR_SHAPE;

@@ -125,6 +125,10 @@ inline int resident_blocks(K kernel, int block_threads, int fallback_per_cu) {
   return per_cu * cu_count();
 }
 
+// hipGetLastError() is sticky across calls: an entry point first drops whatever an unrelated earlier HIP call left
+// behind, so that launch_status() reports THIS launch only.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 
 }  // namespace vqa

@@ -77,6 +77,7 @@ extern "C" {
 
 int vqa_resize_bicubic_h_u8(const uint8_t* src, int h, int w_in, int c, const int32_t* kk, const int32_t* bounds,
                             int ksize, int w_out, uint8_t* dst, vqa_stream_t stream) {
+  clear_stale_error();
   if (!src || !kk || !bounds || !dst) return VQA_ERR_NULL;
   if (h <= 0 || w_in <= 0 || c <= 0 || c > 4 || ksize <= 0 || w_out <= 0) return VQA_ERR_SHAPE;
   const long total = static_cast<long>(h) * w_out * c;
@@ -88,6 +89,7 @@ int vqa_resize_bicubic_h_u8(const uint8_t* src, int h, int w_in, int c, const in
 int vqa_resize_bicubic_v_normalize(const uint8_t* src, int h_in, int w, int c, const int32_t* kk,
                                    const int32_t* bounds, int ksize, int h_out, float mean, float stdv, float* dst,
                                    vqa_stream_t stream) {
+  clear_stale_error();
   if (!src || !dst) return VQA_ERR_NULL;
   if (h_in <= 0 || w <= 0 || c <= 0 || c > 4 || h_out <= 0 || stdv == 0.0f) return VQA_ERR_SHAPE;
   if (!aligned4(dst)) return VQA_ERR_ALIGN;

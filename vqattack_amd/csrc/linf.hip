@@ -237,6 +237,7 @@ int vqa_set_option(int option, int value) {
 
 int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float eps, float cmin, float cmax,
                   unsigned mode, int* flag, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{0.0f, eps, cmin, cmax, mode};
   if (eta) return launch_stream<InitOp>(x, eta, nullptr, out, n, p, flag, stream);
   return launch_stream<InitZeroOp>(x, nullptr, nullptr, out, n, p, flag, stream);
@@ -244,34 +245,40 @@ int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float 
 
 int vqa_linf_fgm(const float* x, const float* g, float* out, size_t n, float eps_iter, float cmin, float cmax,
                  unsigned mode, int* flag, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{eps_iter, 0.0f, cmin, cmax, mode};
   return launch_stream<FgmOp>(x, g, nullptr, out, n, p, flag, stream);
 }
 
 int vqa_linf_step(const float* x, const float* g, const float* x0, float* out, size_t n, float eps_iter,
                   float eps, float cmin, float cmax, unsigned mode, int* flag, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{eps_iter, eps, cmin, cmax, mode};
   return launch_stream<StepOp, true>(x, g, x0, out, n, p, flag, stream);
 }
 
 int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, float eps, float cmin,
                      float cmax, unsigned mode, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{0.0f, eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
   return launch_stream<ProjectOp, false, 2>(adv, x0, nullptr, out, n, p, nullptr, stream);   // x0 is re-read every step
 }
 
 int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
   return launch_stream<ClipEtaOp>(eta, nullptr, nullptr, out, n, p, nullptr, stream);
 }
 
 int vqa_zero_out_clipped_grads(const float* grad, const float* x, float* out, size_t n, float cmin, float cmax,
                                vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{0.0f, 0.0f, cmin, cmax, 0u};
   return launch_stream<ZeroClippedOp, false, 2>(grad, x, nullptr, out, n, p, nullptr, stream);   // x is not read-once
 }
 
 int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream) {
+  clear_stale_error();
   StepParams p{0.0f, eps, 0.0f, 0.0f, 0u};
   return launch_stream<SignScaleOp>(g, nullptr, nullptr, out, n, p, nullptr, stream);
 }

@@ -283,6 +283,7 @@ size_t vqa_reduce_ws_bytes(int batch, size_t n_per_sample) {
 
 int vqa_sumsq_per_sample(const float* t, const float* sub, float* out, int batch, size_t n_per_sample, float* ws,
                          vqa_stream_t stream) {
+  clear_stale_error();
   if (!t || !out || !ws) return VQA_ERR_NULL;
   if (batch < 0 || batch > 65535) return VQA_ERR_SHAPE;
   if (!aligned4(t) || (sub && !aligned4(sub))) return VQA_ERR_ALIGN;
@@ -301,6 +302,7 @@ int vqa_sumsq_per_sample(const float* t, const float* sub, float* out, int batch
 
 int vqa_absmax_ties_per_sample(const float* g, float* amax, float* ties, int batch, size_t n_per_sample, float* ws,
                                vqa_stream_t stream) {
+  clear_stale_error();
   if (!g || !amax || !ties || !ws) return VQA_ERR_NULL;
   if (batch < 0 || batch > 65535) return VQA_ERR_SHAPE;
   if (!aligned4(g)) return VQA_ERR_ALIGN;
@@ -318,12 +320,14 @@ int vqa_absmax_ties_per_sample(const float* g, float* amax, float* ties, int bat
 
 int vqa_l2_fgm(const float* x, const float* g, const float* sumsq_g, float* out, int batch, size_t n_per_sample,
                float eps_iter, float cmin, float cmax, unsigned mode, int* flag, vqa_stream_t stream) {
+  clear_stale_error();
   NormParams p{eps_iter, cmin, cmax, mode};
   return launch_per_sample<kL2Fgm, true>(x, g, sumsq_g, nullptr, out, batch, n_per_sample, p, flag, stream);
 }
 
 int vqa_l2_project(const float* adv, const float* x0, const float* sumsq_eta, float* out, int batch,
                    size_t n_per_sample, float eps, float cmin, float cmax, unsigned mode, vqa_stream_t stream) {
+  clear_stale_error();
   NormParams p{eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
   return launch_per_sample<kL2Project, true>(adv, x0, sumsq_eta, nullptr, out, batch, n_per_sample, p, nullptr,
                                              stream);
@@ -332,12 +336,14 @@ int vqa_l2_project(const float* adv, const float* x0, const float* sumsq_eta, fl
 int vqa_l1_fgm(const float* x, const float* g, const float* amax, const float* ties, float* out, int batch,
                size_t n_per_sample, float eps_iter, float cmin, float cmax, unsigned mode, int* flag,
                vqa_stream_t stream) {
+  clear_stale_error();
   NormParams p{eps_iter, cmin, cmax, mode};
   return launch_per_sample<kL1Fgm, true>(x, g, amax, ties, out, batch, n_per_sample, p, flag, stream);
 }
 
 int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, float* out, int batch,
                          size_t n_per_sample, float eps, int kind, vqa_stream_t stream) {
+  clear_stale_error();
   NormParams p{eps, 0.0f, 0.0f, 0u};
   switch (kind) {
     case 0: return launch_per_sample<kClipEtaL2, false>(t, nullptr, stat, nullptr, out, batch, n_per_sample, p, nullptr, stream);

@@ -339,6 +339,7 @@ int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, 
                      long mask_period, long rows0, long rows1, int D, long a_stride0, long a_stride1,
                      long b_stride0, long b_stride1, long g_stride0, long g_stride1, float gscale, float cos_eps,
                      float* loss_out, int accumulate, vqa_stream_t stream) {
+  clear_stale_error();
   if (!a || !b || !partial) return VQA_ERR_NULL;
   RowAddr ra;
   const int rc = make_row_addr(ra, rows0, rows1, 1, D, a_stride0, a_stride1, b_stride0, b_stride1, g_stride0,
@@ -360,6 +361,7 @@ int vqa_neg_cos_rows_multi(const float* const* a, const float* const* b, float* 
                            long a_stride0, long a_stride1, long b_stride0, long b_stride1, long g_stride0,
                            long g_stride1, float gscale, float cos_eps, float* loss_out, int accumulate,
                            vqa_stream_t stream) {
+  clear_stale_error();
   if (!a || !b || !partial) return VQA_ERR_NULL;
   if (n_layers < 1 || n_layers > kMaxLayers) return VQA_ERR_SHAPE;
   RowAddr ra;
@@ -380,6 +382,7 @@ int vqa_neg_cos_rows_multi(const float* const* a, const float* const* b, float* 
 
 int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
                      vqa_stream_t stream) {
+  clear_stale_error();
   if (!partial || !dst) return VQA_ERR_NULL;
   if (count < 0) return VQA_ERR_SHAPE;
   sum_partials_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(partial, count, dst, accumulate, scale);

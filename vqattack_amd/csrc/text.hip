@@ -173,6 +173,102 @@ __global__ __launch_bounds__(kBlock) void embed_tokens_kernel(const float* __res
   }
 }
 
+
+// Greedy acceptance of update_adv_text for a whole batch, one wavefront per sample, with the bag-of-embeddings
+// sentence similarity (the stand-in for the reference's TF-Hub sentence encoder):
+//     sim(ids) = <m(ori), m(ids)> / (|m(ori)| |m(ids)| + 1e-12),   m(ids) = mean over non-pad tokens of table[id].
+// The sample's candidates are visited in descending dir_sim order; a candidate whose word is still free is accepted
+// iff the similarity of the question with that word replaced exceeds the threshold, which then rises to that
+// similarity (ALBEF_attack/adv_attack.py:299-323).  The current ids live one per lane (L <= 64), the sentence vectors
+// as NE = E/64 floats per lane; every trial re-sums the sentence's rows of the table in token order (L loads per lane,
+// independent, L2-resident), reductions are DPP.  Sequential by nature within a sample, parallel over samples.
+template <int NE>
+__global__ __launch_bounds__(kWave) void greedy_accept_kernel(const int32_t* __restrict__ cand,
+                                                              const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ seg, int L,
+                                                              const int64_t* __restrict__ ori_ids,
+                                                              int64_t* __restrict__ cur_ids, int32_t* __restrict__ new_id,
+                                                              int32_t* __restrict__ acc_rank,
+                                                              const float* __restrict__ table, int V, int E,
+                                                              float threshold) {
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x;
+  const long base = static_cast<long>(s) * L;
+  // lane t keeps token t of the original and of the current question (0 = padding beyond L)
+  long ori_tok = lane < L ? ori_ids[base + lane] : 0;
+  long cur_tok = lane < L ? cur_ids[base + lane] : 0;
+  if (ori_tok < 0 || ori_tok >= V) ori_tok = 0;      // out-of-vocabulary ids count as padding (host validates)
+  if (cur_tok < 0 || cur_tok >= V) cur_tok = 0;
+  int accepted = -1, my_rank = -1, n_acc = 0;         // lane t: id accepted at position t and its acceptance order
+  float ov[NE], tv[NE];
+  // m(ori)
+  int n = 0;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) ov[e] = 0.0f;
+  for (int t = 0; t < L; ++t) {
+    const long id = __shfl(ori_tok, t, kWave);
+    if (id != 0) {
+      ++n;
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (e * kWave + lane < E) ov[e] += table[id * E + e * kWave + lane];
+    }
+  }
+  float oo = 0.0f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    ov[e] = ov[e] / static_cast<float>(n);
+    oo += ov[e] * ov[e];
+  }
+  const float no = sqrtf(wave_sum(oo));
+  float thr = threshold;
+  unsigned long long taken = 0ull;                   // bit p: word at position p already substituted (wave-uniform)
+  const int k1 = seg[s + 1];
+  for (int k = seg[s]; k < k1; ++k) {
+    const int c = order[k];
+    const int p = cand[4 * c + 1], v = cand[4 * c + 3];
+    if (p < 0 || p >= L || v < 0 || v >= V) continue;
+    if ((taken >> p) & 1ull) continue;
+    n = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) tv[e] = 0.0f;
+    for (int t = 0; t < L; ++t) {
+      long id = __shfl(cur_tok, t, kWave);
+      if (t == p) id = v;
+      if (id != 0) {
+        ++n;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          if (e * kWave + lane < E) tv[e] += table[id * E + e * kWave + lane];
+      }
+    }
+    float dot = 0.0f, tt = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      tv[e] = tv[e] / static_cast<float>(n);
+      dot += ov[e] * tv[e];
+      tt += tv[e] * tv[e];
+    }
+    dot = wave_sum(dot);
+    const float sim = dot / (no * sqrtf(wave_sum(tt)) + 1e-12f);
+    if (sim > thr) {                                  // wave-uniform
+      thr = sim;
+      taken |= 1ull << p;
+      if (lane == p) {
+        cur_tok = v;
+        accepted = v;
+        my_rank = n_acc;
+      }
+      ++n_acc;
+    }
+  }
+  if (lane < L) {
+    cur_ids[base + lane] = cur_tok;
+    new_id[base + lane] = accepted;
+    if (acc_rank) acc_rank[base + lane] = my_rank;
+  }
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -181,6 +277,7 @@ extern "C" {
 
 int vqa_gather_rows(const float* src, const int64_t* idx, float* dst, int B, int L, int K, int D,
                     vqa_stream_t stream) {
+  clear_stale_error();
   if (!src || !idx || !dst) return VQA_ERR_NULL;
   if (B < 0 || L <= 0 || K < 0 || D <= 0) return VQA_ERR_SHAPE;
   if (!aligned4(src) || !aligned4(dst)) return VQA_ERR_ALIGN;
@@ -194,6 +291,7 @@ int vqa_gather_rows(const float* src, const int64_t* idx, float* dst, int B, int
 int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                      float ln_eps, const float* e_ori, const float* grad, const int32_t* cand, float* out,
                      int n_cand, int L, int K, int D, vqa_stream_t stream) {
+  clear_stale_error();
   if (!word || !pos || !type || !gamma || !beta || !e_ori || !grad || !cand || !out) return VQA_ERR_NULL;
   if (n_cand < 0 || L <= 0 || K <= 0 || D <= 0 || D > 256 * kMaxCh || (D & 3)) return VQA_ERR_SHAPE;
   if (!aligned16(word) || !aligned16(pos) || !aligned16(type) || !aligned16(gamma) || !aligned16(beta) ||
@@ -221,6 +319,7 @@ int vqa_cand_dir_sim(const float* word, const float* pos, const float* type, con
 
 int vqa_embed_tokens(const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                      float ln_eps, const int32_t* triples, int n, float* dst, int D, vqa_stream_t stream) {
+  clear_stale_error();
   if (!word || !pos || !type || !gamma || !beta || !triples || !dst) return VQA_ERR_NULL;
   if (n < 0 || D <= 0 || D > 256 * kMaxCh || (D & 3)) return VQA_ERR_SHAPE;
   if (!aligned16(word) || !aligned16(pos) || !aligned16(type) || !aligned16(gamma) || !aligned16(beta) ||
@@ -242,6 +341,29 @@ int vqa_embed_tokens(const float* word, const float* pos, const float* type, con
     default: VQA_EMB(8); break;
   }
 #undef VQA_EMB
+  return launch_status();
+}
+
+int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* seg, int B, int L,
+                      const int64_t* ori_ids, int64_t* cur_ids, int32_t* new_id, int32_t* acc_rank, const float* table,
+                      int V, int E, float threshold, vqa_stream_t stream) {
+  clear_stale_error();
+  if (!cand || !order || !seg || !ori_ids || !cur_ids || !new_id || !table) return VQA_ERR_NULL;
+  if (B < 0 || L <= 0 || L > kWave || V <= 0 || E <= 0 || E > kWave * 8) return VQA_ERR_SHAPE;
+  if (!aligned4(table)) return VQA_ERR_ALIGN;
+  if (B == 0) return VQA_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define VQA_ACC(N) \
+  greedy_accept_kernel<N><<<B, kWave, 0, st>>>(cand, order, seg, L, ori_ids, cur_ids, new_id, acc_rank, table, V, E, \
+                                               threshold)
+  switch ((E + kWave - 1) / kWave) {
+    case 1: VQA_ACC(1); break;
+    case 2: VQA_ACC(2); break;
+    case 3: VQA_ACC(3); break;
+    case 4: VQA_ACC(4); break;
+    default: VQA_ACC(8); break;
+  }
+#undef VQA_ACC
   return launch_status();
 }
 

@@ -423,11 +423,14 @@ def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_gr
 
 
 def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want_grad=True, ignore_index=-100,
-                      flag=None, ws=None):
+                      flag=None, ws=None, rows_per_sample=0):
     """loss_out[0] (+)= gscale * sum_k CE_mean(logits, label_sets[k]); returns d(that)/d logits or None.
 
     ``logits`` (..., V) fp32 with dense rows; ``label_sets`` int64 (K, rows) -- K label sets over the same rows
     (K = 1 for the reference's 2-d labels, K = labels.shape[1] for its 3-d labels).
+    ``rows_per_sample``: 0 -> every label set is a mean over ALL rows (``F.cross_entropy`` on the batch, the reference's
+    op); L -> rows are grouped per sample (L consecutive rows) and each sample's label sets are normalised by that
+    sample's own valid-label counts, i.e. the batch-1 reference's loss summed over the samples of a batched attack.
     A label outside ``[0, V)`` that is not ``ignore_index`` makes the loss NaN and sets ``VQA_FLAG_BAD_LABEL`` in
     ``flag`` (int32 device word, optional) -- torch device-asserts there; nothing is silently dropped.
     """
@@ -444,11 +447,14 @@ def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want
     if k > lib().vqa_ce_max_label_sets():
         raise _hip.HipExtensionError("at most {} label sets per launch".format(lib().vqa_ce_max_label_sets()))
     grad = _scratch(ws, "ce_grad", (rows, v), torch.float32, logits.device) if want_grad else None
-    scratch = _scratch(ws, "ce_scratch", (lib().vqa_ce_scratch_floats(),), torch.float32, logits.device)
+    groups = 1 if rows_per_sample in (0, None) or rows == 0 else -(-rows // int(rows_per_sample))
+    scratch = _scratch(ws, "ce_scratch", (max(int(lib().vqa_ce_scratch_floats(k, groups)), 1),), torch.float32,
+                       logits.device)
     row_loss = _scratch(ws, "ce_rows", (max(rows, 1),), torch.float32, logits.device)
     with _on(logits):
         check(lib().vqa_ce_rows(ptr(flat), flat.stride(0), ctypes.c_void_p(label_sets.data_ptr()), k, rows, v,
-                                ignore_index, ptr(scratch), ptr(grad), ptr(row_loss), gscale, ptr(loss_out),
+                                ignore_index, int(rows_per_sample or 0), ptr(scratch), ptr(grad), ptr(row_loss), gscale,
+                                ptr(loss_out),
                                 1 if accumulate else 0, ptr(flag), stream_for(logits)), "vqa_ce_rows")
     return grad.reshape(logits.shape) if want_grad else None
 
@@ -528,3 +534,43 @@ def embed_tokens(tables, text_ids, out=None, rows=None):
                                      ptr(tables["beta"]), tables["ln_eps"], ctypes.c_void_p(triples.data_ptr()),
                                      triples.shape[0], ptr(out), d, stream_for(word)), "vqa_embed_tokens")
     return out
+
+
+def greedy_accept(cand, scores, ori_ids, cur_ids, table, threshold):
+    """Device-side acceptance of one substitution round (``vqa_greedy_accept``); no host synchronisation.
+
+    ``cand`` int32 (n, 4) device rows {sample, position, grad row, id}; ``scores`` fp32 (n,) their dir_sim;
+    ``ori_ids`` / ``cur_ids`` int64 (B, L) device (``cur_ids`` is updated IN PLACE); ``table`` fp32 (V, E) sentence-encoder
+    stand-in.  Returns ``(new_id, rank)`` int32 (B, L): the accepted id per position (-1 elsewhere) and the order in which
+    the sample accepted it."""
+    dev_f32(table, "table"), dev_f32(scores, "scores")
+    if cand.dtype != torch.int32 or cand.dim() != 2 or cand.shape[1] != 4 or not cand.is_cuda:
+        raise TypeError("cand must be an int32 (n, 4) device tensor")
+    for name, t in (("ori_ids", ori_ids), ("cur_ids", cur_ids)):
+        if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+            raise TypeError("{} must be a contiguous int64 (B, L) device tensor".format(name))
+    b, l = cur_ids.shape
+    if tuple(ori_ids.shape) != (b, l):
+        raise ValueError("ori_ids / cur_ids shape mismatch")
+    if l > 64:
+        raise _hip.HipExtensionError("vqa_greedy_accept holds one token per lane: L <= 64, got {}".format(l))
+    cand = cand.contiguous()
+    n = cand.shape[0]
+    # candidates grouped by sample, best dir_sim first; both sorts are stable, so ties keep their proposal order like
+    # python's sorted(..., reverse=True) in the reference
+    by_score = torch.argsort(scores, descending=True, stable=True)
+    by_sample = torch.argsort(cand[by_score, 0], stable=True)
+    order = by_score[by_sample].to(torch.int32).contiguous()
+    counts = torch.bincount(cand[:, 0].to(torch.int64), minlength=b)[:b] if n else torch.zeros(b, dtype=torch.int64,
+                                                                                               device=cur_ids.device)
+    seg = torch.zeros(b + 1, dtype=torch.int32, device=cur_ids.device)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    new_id = torch.empty((b, l), dtype=torch.int32, device=cur_ids.device)
+    rank = torch.empty((b, l), dtype=torch.int32, device=cur_ids.device)
+    with _on(cur_ids):
+        check(lib().vqa_greedy_accept(ctypes.c_void_p(cand.data_ptr()), ctypes.c_void_p(order.data_ptr()),
+                                      ctypes.c_void_p(seg.data_ptr()), b, l, ctypes.c_void_p(ori_ids.data_ptr()),
+                                      ctypes.c_void_p(cur_ids.data_ptr()), ctypes.c_void_p(new_id.data_ptr()),
+                                      ctypes.c_void_p(rank.data_ptr()), ptr(table), table.shape[0], table.shape[1],
+                                      float(threshold), stream_for(cur_ids)), "vqa_greedy_accept")
+    return new_id, rank

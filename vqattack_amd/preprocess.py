@@ -115,6 +115,11 @@ class ImagePreprocessor:
                 ev.record(self._copy_stream)
                 staged.append((t, ev))
         st = ctypes.c_void_p(main.cuda_stream)
+        with torch.cuda.device(self.device):      # the kernels launch on the CURRENT device: make it self.device
+            self._resample(staged, main, st, out, s)
+        return out
+
+    def _resample(self, staged, main, st, out, s):
         for b, (src, ev) in enumerate(staged):
             main.wait_event(ev)
             h, w, c = src.shape
