@@ -42,11 +42,12 @@ const char* vqa_error_string(int code);
 
 /* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
  *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
- *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores (default 1)
+ *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores, bit2 = first/third-stream
+ *             loads, bit3 = result stores only when the result exceeds the 256 MB Infinity Cache (default 1|4|8 = 13)
  *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
  *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup
- *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 256)
- *   option 5: workgroups of the cross-entropy kernel resident per CU (2 = default, 3 = tighter register budget)
+ *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 512)
+ *   option 5: reserved (accepts 2)
  *   option 6: grid of the cosine-loss kernel, 0 = exactly the resident workgroups (occupancy x CUs, default),
  *             n = 1..8 workgroups per CU
  *   option 7: rows in flight per wavefront in the cosine-loss kernel (1 or 2; default 2)

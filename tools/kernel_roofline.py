@@ -83,6 +83,12 @@ def copy_probes(x, x0, g, out, n):
 
 
 def linf_section(x, x0, g, eta, out, n):
+    for nt in (1, 3, 5, 7, 13):
+        assert _hip.lib().vqa_set_option(1, nt) == 0
+        report("vqa_linf_step [nt mask {}: grad loads {}, stores {}, x/x0 loads {}]".format(
+            nt, "nt" if nt & 1 else "plain", "nt" if nt & 2 else ("nt above 256 MB" if nt & 8 else "plain"),
+            "nt" if nt & 4 else "plain"), 16 * n,
+            timeit(lambda: ops.linf_step(x, g, x0, 0.01, 0.125, -1, 1, out=out)), "A/B knob sweep")
     report("vqa_linf_step", 16 * n, timeit(lambda: ops.linf_step(x, g, x0, 0.01, 0.125, -1, 1, out=out)))
     def eager_chain():
         # the reference's op chain between two model calls, as PyTorch-ROCm runs it (SURVEY.md section 2.3, rows 1-13
@@ -176,14 +182,14 @@ def ce_section(b):
     labels = torch.randint(0, 30522, (1, rows), device="cuda")
     labels3 = torch.randint(0, 30522, (3, rows), device="cuda")
     ws = ops.Workspace()
-    for per_cu, threads in ((2, 256), (3, 256), (2, 512)):
-        assert _hip.lib().vqa_set_option(5, per_cu) == 0 and _hip.lib().vqa_set_option(4, threads) == 0
-        tag = "{} workgroups/CU, {} threads".format(per_cu, threads)
+    for variant, threads in ((2, 256), (2, 512), (3, 512)):
+        assert _hip.lib().vqa_set_option(4, threads) == 0 and _hip.lib().vqa_set_option(5, variant) == 0
+        tag = "{} threads, {} logits loads".format(threads, "nt" if variant == 3 else "plain")
         report("vqa_ce_rows (loss+grad, K=1) [{}]".format(tag), 8 * rows * 30522,
                timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, ws=ws)))
         report("vqa_ce_rows (loss+grad, K=1) [{}], row losses only (no in-kernel fold)".format(tag), 8 * rows * 30522,
                timeit(lambda: ops.mlm_cross_entropy(logits, labels, None, accumulate=False, ws=ws)), "A/B")
-    assert _hip.lib().vqa_set_option(5, 2) == 0 and _hip.lib().vqa_set_option(4, 256) == 0      # defaults
+    assert _hip.lib().vqa_set_option(4, 512) == 0 and _hip.lib().vqa_set_option(5, 2) == 0      # defaults
     report("vqa_ce_rows (loss+grad, K=3)", 8 * rows * 30522,
            timeit(lambda: ops.mlm_cross_entropy(logits, labels3, slot, accumulate=False, ws=ws)))
     report("vqa_ce_rows (loss only, K=1)", 4 * rows * 30522,

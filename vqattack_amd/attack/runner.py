@@ -173,7 +173,7 @@ class BatchedVQAttack:
             e_ori = ops.embed_tokens(self.tables, text_ids)
             adv_emb = e_ori.clone()
             ori_ids = text_ids.contiguous()
-            positions = list(range(text_ids.shape[1]))
+            positions = ops.RowIndex(range(text_ids.shape[1]), text_ids.shape[1], dev)   # probe mask, uploaded once
             for bi, steps in enumerate(blocks):
                 a.set_text(adv_ids, text_masks, text_ids_mlm=mlm_ids, text_mask_mlm=mlm_mask)
                 with torch.enable_grad():

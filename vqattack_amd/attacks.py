@@ -471,6 +471,8 @@ def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, cli
     text_grad = None
     loss_buf = torch.zeros(max(nb_iter, 1), dtype=torch.float32, device=img.device)
     ws = ops.Workspace()
+    if attack_mask is not None and not isinstance(attack_mask, ops.RowIndex):   # validated + uploaded once per call
+        attack_mask = ops.RowIndex(attack_mask, emb.shape[1], emb.device)
     for it in range(nb_iter):
         leaf_img = adv.detach().requires_grad_(True)
         leaf_txt = emb.detach().requires_grad_(True)

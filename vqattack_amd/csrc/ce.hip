@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
 // head, a 16-byte aligned body of float4 and a <= 3 element tail (8-byte accesses run at 0.54-0.70x the 16-byte rate
 // on this chip, MI355X_MICROARCH.md).  Lane t < head owns x[t]; lane 8 + t owns tail element t.
 constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
-static int g_ce_threads = 256;        // vqa_set_option(4, 256 | 512 | 1024)
-static int g_ce_variant = 2;          // vqa_set_option(5, n): n = workgroups resident per CU (2 or 3; 3 only at 256 threads)
+static int g_ce_threads = 512;        // vqa_set_option(4, 256 | 512 | 1024); 512 measured 2-3 % ahead of 256 (profiles/r02)
+static int g_ce_variant = 2;          // vqa_set_option(5, 2): reserved (the A/B variants of round 2 are gone)
 
 struct RowGeom {
   const f32x4* x4;      // aligned body
@@ -244,8 +244,9 @@ __device__ __forceinline__ int edge_index(const RowGeom& g, int V) {
 // One workgroup per row; WGPC workgroups are resident per CU (launch bounds), so one row's reduce / exp phase overlaps
 // the HBM phases of the others.  (A persistent variant that streamed row r's gradient out while loading row r + grid
 // into the same registers measured 5-8 % slower: the loads then issue behind the store's VALU work instead of in one
-// burst at workgroup start -- profiles/r02/kernel_roofline_ab_b64.jsonl.)
-template <bool GRAD, int MAXK, int THREADS, int WGPC>
+// burst at workgroup start -- profiles/r02/kernel_roofline_ab_b64.jsonl; three workgroups per CU at a 168-VGPR budget
+// measured 5-7 % slower than two -- profiles/r02/kernel_roofline_ab2_b64.jsonl.)
+template <bool GRAD, int MAXK, int THREADS, int WGPC, bool NTL>
 __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels, int K, long rows, int V, long ignore_index,
     CeNorm norm, float* __restrict__ grad, float* __restrict__ row_loss, float gscale,
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
 #pragma unroll
   for (int i = 0; i < kQuads; ++i) {
     const int j = i * THREADS + threadIdx.x;
-    v[i] = (j < cur.nquad) ? cur.x4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    v[i] = (j < cur.nquad) ? (NTL ? __builtin_nontemporal_load(cur.x4 + j) : cur.x4[j])
+                           : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   }
   const int edge = edge_index(cur, V);
   float ve = (edge >= 0) ? cur.x[edge] : -INFINITY;
@@ -328,12 +330,11 @@ template <bool GRAD, int MAXK, int THREADS>
 static void launch_reg(int variant, long rows, hipStream_t st, const float* logits, const int64_t* labels, int K, int V,
                        long ignore_index, const CeNorm& norm, float* grad, float* row_loss, float gscale,
                        int* flag, const CeFold& fold) {
-  const int grid = static_cast<int>(rows);
-  if (variant == 3 && THREADS == 256)     // 3 workgroups per CU: 168 VGPRs per lane, the 128-register row still fits
-    ce_rows_reg_kernel<GRAD, MAXK, THREADS, (THREADS == 256 ? 3 : 2)><<<grid, THREADS, 0, st>>>(
+  if (variant == 3)     // A/B: logits loaded non-temporally (they are read exactly once)
+    ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2, true><<<static_cast<int>(rows), THREADS, 0, st>>>(
         logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
   else
-    ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2><<<grid, THREADS, 0, st>>>(
+    ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2, false><<<static_cast<int>(rows), THREADS, 0, st>>>(
         logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
 }
 

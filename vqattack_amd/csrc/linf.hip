@@ -13,7 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- tuning knobs (vqa_set_option), defaults chosen from the round-1 sweep recorded in DESIGN.md
 static int g_opt_blocks_per_cu = 8;   // option 0
-static int g_opt_nontemporal = 1;     // option 1: bit0 = nt loads of g, bit1 = nt stores of out (in-situ A/B)
+// option 1: bit0 = nt loads of the second stream (the gradient: read exactly once), bit1 = nt stores of the result,
+// bit2 = nt loads of the first and third stream (x, x0), bit3 = nt stores only when the result is larger than the
+// 256 MB Infinity Cache (a smaller result is re-read from the cache by the white box's next forward; a larger one
+// cannot stay resident anyway and the plain-store allocation only costs bandwidth: tools/stream_probe, +10 % at 1.8 GB)
+static int g_opt_nontemporal = 1 | 4 | 8;
+constexpr size_t kNtStoreBytes = 256ull << 20;
 static int g_opt_unroll = 4;          // option 2: 16-byte tiles in flight per lane and stream (2, 4 or 8)
 static int g_opt_chunked = 0;         // option 3: 0 = grid-stride tiles, 1 = one contiguous chunk per workgroup
 
@@ -90,7 +95,7 @@ struct SignScaleOp {
 
 // ---- 16-byte streaming kernel -----------------------------------------------------------------
 // NT bit0: the second stream (the gradient, read exactly once) is loaded non-temporally;
-// NT bit1: the result is stored non-temporally.
+// NT bit1: the result is stored non-temporally; NT bit2: the first and third stream are loaded non-temporally.
 template <class Op, int U, int NT>
 __global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // may alias out (in-place update)
                                                          const f32x4* __restrict__ s1,
@@ -110,9 +115,9 @@ __global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // ma
     for (int u = 0; u < U; ++u) {
       const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
       if (i < last) {
-        v0[u] = s0[i];
+        v0[u] = (NT & 4) ? __builtin_nontemporal_load(&s0[i]) : s0[i];
         if (Op::kIn > 1) v1[u] = (NT & 1) ? __builtin_nontemporal_load(&s1[i]) : s1[i];
-        if (Op::kIn > 2) v2[u] = s2[i];
+        if (Op::kIn > 2) v2[u] = (NT & 4) ? __builtin_nontemporal_load(&s2[i]) : s2[i];
       }
     }
 #pragma unroll
@@ -151,16 +156,20 @@ __global__ __launch_bounds__(kBlock) void stream1_kernel(const float* s0,
 template <class Op, int U>
 static void launch_vec(int nt, int grid, hipStream_t st, const f32x4* a0, const f32x4* a1, const f32x4* a2, f32x4* o,
                        size_t n4, const StepParams& p, int* flag, size_t chunk) {
-  switch (nt & 3) {
+  switch (nt & 7) {
     case 0: stream4_kernel<Op, U, 0><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     case 2: stream4_kernel<Op, U, 2><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
-    default: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 3: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 4: stream4_kernel<Op, U, 4><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 5: stream4_kernel<Op, U, 5><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 6: stream4_kernel<Op, U, 6><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    default: stream4_kernel<Op, U, 7><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
   }
 }
 
 // NTMASK restricts the non-temporal hints an op may use: bit0 only makes sense when the second stream is read once.
-template <class Op, bool TUNABLE = false, int NTMASK = 3>
+template <class Op, bool TUNABLE = false, int NTMASK = 7>
 static int launch_stream(const float* s0, const float* s1, const float* s2, float* out, size_t n,
                          const StepParams& p, int* flag, vqa_stream_t stream) {
   if (!s0 || !out || (Op::kIn > 1 && !s1) || (Op::kIn > 2 && !s2)) return VQA_ERR_NULL;
@@ -184,9 +193,13 @@ static int launch_stream(const float* s0, const float* s1, const float* s2, floa
     auto a1 = reinterpret_cast<const f32x4*>(s1);
     auto a2 = reinterpret_cast<const f32x4*>(s2);
     auto o = reinterpret_cast<f32x4*>(out);
-    if (TUNABLE && unroll == 2) launch_vec<Op, 2>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
-    else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
-    else launch_vec<Op, 4>(g_opt_nontemporal & NTMASK, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    int nt = g_opt_nontemporal & 7;
+    if ((g_opt_nontemporal & 8) && n * sizeof(float) > kNtStoreBytes) nt |= 2;
+    nt &= NTMASK;
+    if (s0 == out) nt &= ~4;        // in-place update: the first stream is about to be rewritten, keep it plain
+    if (TUNABLE && unroll == 2) launch_vec<Op, 2>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else launch_vec<Op, 4>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
     done = n4 * 4;
   }
   if (done < n) {
@@ -213,7 +226,7 @@ int vqa_set_option(int option, int value) {
       g_opt_blocks_per_cu = value;
       return VQA_OK;
     case 1:
-      g_opt_nontemporal = value & 3;
+      g_opt_nontemporal = value & 15;
       return VQA_OK;
     case 2:
       if (value != 2 && value != 4 && value != 8) return VQA_ERR_SHAPE;
@@ -261,7 +274,7 @@ int vqa_linf_project(const float* adv, const float* x0, float* out, size_t n, fl
                      float cmax, unsigned mode, vqa_stream_t stream) {
   clear_stale_error();
   StepParams p{0.0f, eps, cmin, cmax, mode & ~VQA_CHECK_RANGE};
-  return launch_stream<ProjectOp, false, 2>(adv, x0, nullptr, out, n, p, nullptr, stream);   // x0 is re-read every step
+  return launch_stream<ProjectOp, false, 7>(adv, x0, nullptr, out, n, p, nullptr, stream);
 }
 
 int vqa_clip_eta_linf(const float* eta, float* out, size_t n, float eps, vqa_stream_t stream) {
@@ -274,7 +287,7 @@ int vqa_zero_out_clipped_grads(const float* grad, const float* x, float* out, si
                                vqa_stream_t stream) {
   clear_stale_error();
   StepParams p{0.0f, 0.0f, cmin, cmax, 0u};
-  return launch_stream<ZeroClippedOp, false, 2>(grad, x, nullptr, out, n, p, nullptr, stream);   // x is not read-once
+  return launch_stream<ZeroClippedOp, false, 7>(grad, x, nullptr, out, n, p, nullptr, stream);
 }
 
 int vqa_optimize_linear_linf(const float* g, float* out, size_t n, float eps, vqa_stream_t stream) {

@@ -460,18 +460,35 @@ def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want
 
 
 # ----------------------------------------------------------------------------------------- text side
+class RowIndex:
+    """A validated, device-resident int64 index for ``gather_rows`` (``text_emb_pick`` / ``attack_mask``): build it once
+    per attack and reuse it every iteration -- no per-call host check, no host->device copy, and a device-tensor index
+    is read back exactly once."""
+
+    def __init__(self, index, length, device):
+        if not isinstance(index, torch.Tensor):
+            index = torch.as_tensor(list(index), dtype=torch.int64)
+        host = index.detach().cpu().to(torch.int64).reshape(-1)
+        if host.numel() and (int(host.max()) >= length or int(host.min()) < -length):
+            raise IndexError("index out of range for dimension 1 with size {}".format(length))
+        self.length = length
+        self.device_index = host.to(device)
+
+    def __len__(self):
+        return self.device_index.numel()
+
+
 def gather_rows(src, index):
-    """src (B, L, D)[:, index] -> (B, K, D)."""
+    """src (B, L, D)[:, index] -> (B, K, D).  ``index``: list / tensor (validated on every call) or a ``RowIndex``."""
     dev_f32(src, "text gradient")
     if src.dim() != 3:
         raise ValueError("text gradient must be (B, L, D)")
-    if not isinstance(index, torch.Tensor):
-        index = torch.as_tensor(list(index), dtype=torch.int64)
     b, l, d = src.shape
-    host = index.detach().cpu().to(torch.int64)
-    if host.numel() and (int(host.max()) >= l or int(host.min()) < -l):
-        raise IndexError("index out of range for dimension 1 with size {}".format(l))
-    idx = host.to(src.device)
+    if not isinstance(index, RowIndex):
+        index = RowIndex(index, l, src.device)
+    elif index.length != l or index.device_index.device != src.device:
+        raise ValueError("RowIndex was prepared for length {} on {}".format(index.length, index.device_index.device))
+    idx = index.device_index
     k = idx.numel()
     dst = torch.empty((b, k, d), dtype=torch.float32, device=src.device)
     if k == 0 or b == 0:
