@@ -30,7 +30,8 @@ def _worker(rank, world, port, n_samples, out_dir):
                 ledger.record(torch.tensor([i % 3 == 0 for i in chunk]), sample_ids=chunk)
         bits, ids = ledger.all_gather_bits()
         rate = ledger.all_gather_rate()
-        torch.save({"bits": bits, "ids": ids, "rate": rate}, os.path.join(out_dir, "r{}.pt".format(rank)))
+        torch.save({"bits": bits, "ids": ids, "rate": rate, "running": ledger.running_rate()},
+                   os.path.join(out_dir, "r{}.pt".format(rank)))
     finally:
         dist.destroy_process_group()
 
@@ -44,7 +45,7 @@ def test_two_rank_success_gather(tmp_path, n_samples):
         got = torch.load(os.path.join(str(tmp_path), "r{}.pt".format(rank)))
         assert sorted(got["ids"].tolist()) == list(range(n_samples))        # every sample exactly once
         assert all(bool(b) == (i % 3 == 0) for b, i in zip(got["bits"].tolist(), got["ids"].tolist()))
-        assert abs(got["rate"] - want) < 1e-6
+        assert abs(got["rate"] - want) < 1e-6 and abs(got["running"] - want) < 1e-6
 
 
 def test_shards_partition_the_sweep():

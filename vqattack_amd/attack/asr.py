@@ -69,6 +69,16 @@ class SuccessLedger:
             all_ids = torch.cat([p[:c] for p, c in zip(iparts, counts)])
         return all_bits, all_ids
 
+    def running_rate(self):
+        """Attack accuracy so far over ALL ranks: one ``all_reduce(SUM)`` of (successes, samples) -- the running
+        ``print('attack_accuracy', sum(acc_list) / len(acc_list))`` of the reference (adv_attack.py:732-733) for a sharded
+        sweep.  Collective: every rank must call it at the same point."""
+        bits = self.local_bits()
+        pair = torch.tensor([float(bits.sum().item()), float(bits.numel())], device=self.device, dtype=torch.float64)
+        if self.world > 1 or self.force_collective:
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+        return float(pair[0] / pair[1]) if float(pair[1]) > 0 else None
+
     def all_gather_rate(self):
         """Attack success rate over every rank's samples (the reference's final ``sum(acc_list)/len(acc_list)``)."""
         bits, _ = self.all_gather_bits()

@@ -330,7 +330,11 @@ template <bool GRAD, int MAXK, int THREADS>
 static void launch_reg(int variant, long rows, hipStream_t st, const float* logits, const int64_t* labels, int K, int V,
                        long ignore_index, const CeNorm& norm, float* grad, float* row_loss, float gscale,
                        int* flag, const CeFold& fold) {
-  if (variant == 3)     // A/B: logits loaded non-temporally (they are read exactly once)
+  // logits are read exactly once: beyond twice the 256 MB Infinity Cache a non-temporal load is 5 % ahead (2.5 GB:
+  // 474 vs 497 us), below it the plain load still finds part of the producer GEMM's output in the cache (625 MB: 119
+  // vs 122 us) -- profiles/r02/kernel_roofline_nt_b{64,256}.jsonl.  variant 3 forces nt (A/B).
+  const bool big = static_cast<size_t>(rows) * V * sizeof(float) > (512ull << 20);
+  if (variant == 3 || big)
     ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2, true><<<static_cast<int>(rows), THREADS, 0, st>>>(
         logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
   else

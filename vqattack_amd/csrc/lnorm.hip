@@ -127,10 +127,18 @@ __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict_
   float m = 0.0f;   // |g| >= 0; NaN is ignored by fmaxf exactly as it never equals the max in the reference
   if (VEC) {
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
-    for (size_t i = lo / 4 + threadIdx.x; i < hi / 4; i += kBlock) {
-      f32x4 v = g4[i];
+    const size_t hi4 = hi / 4;
+    for (size_t i = lo / 4 + threadIdx.x; i < hi4; i += static_cast<size_t>(kBlock) * kRedU) {
+      f32x4 v[kRedU];                         // kRedU 16-byte loads in flight per lane, like sumsq_stage1
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(v[k]));
+      for (int u = 0; u < kRedU; ++u) {
+        const size_t j = i + static_cast<size_t>(u) * kBlock;
+        v[u] = (j < hi4) ? g4[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int u = 0; u < kRedU; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(v[u][k]));
     }
   } else {
     for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) m = fmaxf(m, fabsf(g[base + i]));
