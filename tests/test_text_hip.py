@@ -216,3 +216,45 @@ def test_black_box_answers_equal_per_question_oracle(size):
             vwant += bb.vlmo_predict(vblack.vqa_classifier(vblack.pooled(states)))
     vgot = vblack.to(DEV).vqa_answer(vimages.to(DEV), vids.to(DEV), vmasks.to(DEV)).tolist()
     assert vgot == vwant
+
+
+@pytest.mark.parametrize("flavor", ["albef", "vlmo"])
+def test_mixed_schedule_batch_equals_reference_loops(gold, flavor):
+    """Two samples with DIFFERENT schedules (6 substitutable words / none) attacked as ONE batch by ``attack_mixed``
+    (prefix scheduling, per-sample probe steps, acceptance on the device) vs the reference's own per-sample loop runs:
+    each sample's adversarial text, image and step count must be what the reference produced for it alone."""
+    z, meta = gold
+    model = build_model(flavor, meta).to(DEV)
+    if flavor == "albef":
+        from vqattack_amd.whitebox.albef import AlbefAttackAdapters as Adapters
+    else:
+        from vqattack_amd.whitebox.vlmo import VlmoAttackAdapters as Adapters
+    cases = [c for c in meta["loop_" + flavor]["cases"] if c["old_alg"] == 1]
+    assert len(cases) == 2 and cases[0]["iter_list"] != cases[1]["iter_list"]
+    parts = [_case_inputs(z, meta, flavor, c, model) for c in cases]
+    length = max(p[3].shape[1] for p in parts)
+
+    def pad(t, fill=0):
+        out = torch.full((1, length), fill, dtype=t.dtype)
+        out[:, :t.shape[1]] = t
+        return out
+
+    ids = torch.cat([pad(p[3]) for p in parts]).to(DEV)
+    masks = torch.cat([pad(p[4]) for p in parts]).to(DEV)
+    attackable = torch.cat([pad(p[1]) for p in parts]).to(DEV)
+    proposals = [p[0][0] for p in parts]
+    images = torch.cat([torch.from_numpy(z[c["key"] + "_image"]) for c in cases]).to(DEV)
+    eta = torch.cat([torch.from_numpy(z[c["key"] + "_eta"]) for c in cases]).to(DEV)
+    sim = text_update.BagOfEmbeddingsSimilarity(table=z["use_table"])
+    attack = BatchedVQAttack(Adapters(model), flavor, model.embedding_tables(), AttackConfig(sanity_checks=True),
+                             similarity_fn=sim)
+    res = attack.attack_mixed(images, ids, masks, attackable, init_eta=eta, proposals=proposals)
+    assert res.gradient_steps == sum(40 + int(a.sum()) for a in attackable)
+    for s, c in enumerate(cases):
+        n = len(c["adv_text_ids"])
+        assert res.adv_text_ids[s, :n].tolist() == c["adv_text_ids"], (c["name"], c["adv_text"])
+        want = torch.from_numpy(z[c["key"] + "_adv"])[0]
+        got = res.adv_images[s].cpu()
+        same = float((got == want).float().mean())
+        assert same >= 0.995, (c["name"], same)
+        assert float((got - want).abs().max()) <= 2 * 0.01 * (40 + int(attackable[s].sum())) + 1e-6
