@@ -47,7 +47,8 @@ const char* vqa_error_string(int code);
  *   option 2: 16-byte tiles in flight per lane and stream in vqa_linf_step (2, 4 or 8; default 4)
  *   option 3: tile-to-workgroup mapping, 0 = round-robin tiles (default), 1 = one contiguous chunk per workgroup
  *   option 4: workgroup size of the register-resident cross-entropy kernel (256, 512 or 1024; default 512)
- *   option 5: reserved (accepts 2)
+ *   option 5: logits loads of the cross-entropy kernel, 2 = non-temporal only above 512 MB of logits (default),
+ *             3 = always non-temporal (A/B measurements)
  *   option 6: grid of the cosine-loss kernel, 0 = exactly the resident workgroups (occupancy x CUs, default),
  *             n = 1..8 workgroups per CU
  *   option 7: rows in flight per wavefront in the cosine-loss kernel (1 or 2; default 2)

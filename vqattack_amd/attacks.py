@@ -144,7 +144,7 @@ def _feature_loss_backward(pairs, slot, leaves, sign, extra_scale=1.0, extra=Non
             ga = ops.neg_cos_rows_multi([outs[i].detach() for i in idx], [tgts[i] for i in idx], slot.word,
                                         accumulate=not first, gscale=gscale, want_grad=needs_grad, row_weight=w,
                                         weight_period=period,      # ONE launch for all layers of this modality
-                                        ws=None if ws is None else ops._Sub(ws, pair_index))
+                                        ws=None if ws is None else ops.SubWorkspace(ws, pair_index))
             first = False
             if needs_grad:
                 tensors += [outs[i] for i in idx]

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
 // on this chip, MI355X_MICROARCH.md).  Lane t < head owns x[t]; lane 8 + t owns tail element t.
 constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
 static int g_ce_threads = 512;        // vqa_set_option(4, 256 | 512 | 1024); 512 measured 2-3 % ahead of 256 (profiles/r02)
-static int g_ce_variant = 2;          // vqa_set_option(5, 2): reserved (the A/B variants of round 2 are gone)
+static int g_ce_variant = 2;          // vqa_set_option(5, 2 | 3): 2 = size-aware non-temporal logits loads, 3 = always
 
 struct RowGeom {
   const f32x4* x4;      // aligned body

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(kBlock) void sum_stage2(const float* __restrict__ w
 }
 
 // ---- stage 1/2: max |g| and the number of elements attaining it ---------------------------------
+// Stage 1 reads its chunk from HBM exactly once: the chunk is swept in register-resident tiles (kTieU 16-byte pieces per
+// lane); per tile the workgroup reduces the maximum and counts the elements that attain it from the SAME registers,
+// then merges (max, count) into the chunk's running pair -- no second sweep through L2.
+constexpr int kTieU = 8;
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict__ g, float* __restrict__ ws,
                                                         size_t n_per, int chunks, int batch) {
@@ -124,42 +128,47 @@ __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict_
   const size_t base = static_cast<size_t>(blockIdx.y) * n_per;
   size_t lo, hi;
   chunk_bounds(n_per, chunks, lo, hi);
-  float m = 0.0f;   // |g| >= 0; NaN is ignored by fmaxf exactly as it never equals the max in the reference
+  float run_max = 0.0f, run_cnt = 0.0f;   // |g| >= 0; NaN is ignored by fmaxf exactly as it never equals the max in the reference
   if (VEC) {
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
     const size_t hi4 = hi / 4;
-    for (size_t i = lo / 4 + threadIdx.x; i < hi4; i += static_cast<size_t>(kBlock) * kRedU) {
-      f32x4 v[kRedU];                         // kRedU 16-byte loads in flight per lane, like sumsq_stage1
+    for (size_t t0 = lo / 4; t0 < hi4; t0 += static_cast<size_t>(kBlock) * kTieU) {
+      f32x4 v[kTieU];
+      float m = 0.0f;
 #pragma unroll
-      for (int u = 0; u < kRedU; ++u) {
-        const size_t j = i + static_cast<size_t>(u) * kBlock;
-        v[u] = (j < hi4) ? g4[j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u = 0; u < kTieU; ++u) {
+        const size_t j = t0 + static_cast<size_t>(u) * kBlock + threadIdx.x;
+        v[u] = (j < hi4) ? g4[j] : f32x4{-1.0f, -1.0f, -1.0f, -1.0f};      // fabsf(-1) never ties with a tile max of 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (j < hi4) m = fmaxf(m, fabsf(v[u][k]));
       }
+      const float tm = block_max(m, lds);
+      float c = 0.0f;
 #pragma unroll
-      for (int u = 0; u < kRedU; ++u)
+      for (int u = 0; u < kTieU; ++u) {
+        const size_t j = t0 + static_cast<size_t>(u) * kBlock + threadIdx.x;
+        if (j < hi4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(v[u][k]));
+          for (int k = 0; k < 4; ++k) c += (fabsf(v[u][k]) == tm) ? 1.0f : 0.0f;
+        }
+      }
+      const float tc = block_sum(c, lds);
+      if (tm > run_max) { run_max = tm; run_cnt = tc; }
+      else if (tm == run_max) run_cnt += tc;
     }
   } else {
+    float m = 0.0f;
     for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) m = fmaxf(m, fabsf(g[base + i]));
+    run_max = block_max(m, lds);
+    float c = 0.0f;
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) c += (fabsf(g[base + i]) == run_max) ? 1.0f : 0.0f;
+    run_cnt = block_sum(c, lds);
   }
-  const float bm = block_max(m, lds);
-  float cnt = 0.0f;
-  if (VEC) {
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
-    for (size_t i = lo / 4 + threadIdx.x; i < hi / 4; i += kBlock) {
-      f32x4 v = g4[i];   // second sweep of the chunk: L2-resident (<= 16 KB per workgroup sweep)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cnt += (fabsf(v[k]) == bm) ? 1.0f : 0.0f;
-    }
-  } else {
-    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) cnt += (fabsf(g[base + i]) == bm) ? 1.0f : 0.0f;
-  }
-  const float bc = block_sum(cnt, lds);
   if (threadIdx.x == 0) {
     const size_t slot = static_cast<size_t>(blockIdx.y) * chunks + blockIdx.x;
-    ws[slot] = bm;
-    ws[static_cast<size_t>(batch) * chunks + slot] = (lo < hi) ? bc : 0.0f;
+    ws[slot] = run_max;
+    ws[static_cast<size_t>(batch) * chunks + slot] = (lo < hi) ? run_cnt : 0.0f;
   }
 }
 

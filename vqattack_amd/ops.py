@@ -367,7 +367,7 @@ def neg_cos_rows(a, b, loss_out, accumulate, gscale=1.0, want_grad=True, row_wei
     return ga
 
 
-class _Sub:
+class SubWorkspace:
     """A view of a Workspace whose keys are prefixed (per-layer fallback launches must not share one buffer)."""
 
     def __init__(self, ws, tag):
@@ -394,7 +394,7 @@ def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_gr
         grads = []
         for k, (a, b) in enumerate(zip(a_list, b_list)):
             grads.append(neg_cos_rows(a, b, loss_out, accumulate or k > 0, gscale, want_grad, row_weight, weight_period,
-                                      ws=None if ws is None else _Sub(ws, k)))
+                                      ws=None if ws is None else SubWorkspace(ws, k)))
         return grads if want_grad else None
     r0, r1, d, sa0, sa1 = _rows_view(a0, "out")
     _, _, _, sb0, sb1 = _rows_view(b0, "y")
