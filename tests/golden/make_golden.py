@@ -80,7 +80,8 @@ class ReferenceImpl:
         return self._m(flavor)["pgd_vl"].projected_gradient_descent
 
 
-def main():
+def main(out=None):
+    out = out or OUT
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
     from tests.golden.cases import ALL_CASES, UTIL_CASES, run_case, util_input
 
@@ -102,8 +103,8 @@ def main():
         fn = vl_utils.clip_eta if case["op"] == "clip_eta" else None
         got = fn(t.clone(), norm, case["eps"]) if fn else vl_utils.optimize_linear(t.clone(), case["eps"], norm)
         assert np.array_equal(got.numpy(), blob[case["name"] + "/out"], equal_nan=True), case["name"]
-    np.savez_compressed(OUT, **blob)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    np.savez_compressed(out, **blob)
+    print("wrote", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":

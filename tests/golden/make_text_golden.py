@@ -300,7 +300,8 @@ def section_update(world, arrays, meta):
     meta["updmlm_cases"] = out
 
 
-def main():
+def main(out_npz=None, out_json=None):
+    out_npz, out_json = out_npz or OUT_NPZ, out_json or OUT_JSON
     torch.manual_seed(0)
     world = World()
     arrays, meta = {}, {}
@@ -316,11 +317,11 @@ def main():
     section_update(world, arrays, meta)
     from tests.golden import make_text_golden_tasks as tasks
     tasks.run(world, arrays, meta)
-    np.savez_compressed(OUT_NPZ, **arrays)
-    with open(OUT_JSON, "w") as fh:
+    np.savez_compressed(out_npz, **arrays)
+    with open(out_json, "w") as fh:
         json.dump(meta, fh, indent=1, sort_keys=True)
-    print("wrote", OUT_NPZ, "({} arrays, {:.1f} KB)".format(len(arrays), os.path.getsize(OUT_NPZ) / 1024))
-    print("wrote", OUT_JSON, "({:.1f} KB)".format(os.path.getsize(OUT_JSON) / 1024))
+    print("wrote", out_npz, "({} arrays, {:.1f} KB)".format(len(arrays), os.path.getsize(out_npz) / 1024))
+    print("wrote", out_json, "({:.1f} KB)".format(os.path.getsize(out_json) / 1024))
 
 
 if __name__ == "__main__":
