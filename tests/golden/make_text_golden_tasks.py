@@ -185,6 +185,10 @@ LOOP_CASES = [
     ("dual_words", "is the man holding a red umbrella", "red", ["red", "blue"], "the umbrella is red.", 12),
     ("feat_nowords", "is the", "zebra", ["zebra"], "the animal is a giraffe.", 13),
     ("dual_nowords", "is the", "red", ["red"], "the umbrella is red.", 14),
+    # multi-piece words ("cats" = cat ##s, not substitutable) next to substitutable ones
+    ("feat_pieces", "how many cats are playing on the table", "zebra", ["zebra"], "the animal is a giraffe.", 15),
+    # dual loss with THREE label sets (3-d labels): two alternative answers of the same piece count
+    ("dual_3d_labels", "what color is the kite", "blue", ["blue", "green", "red"], "the color of the kite is blue.", 16),
 ]
 
 

@@ -220,7 +220,7 @@ def test_black_box_answers_equal_per_question_oracle(size):
 
 @pytest.mark.parametrize("flavor", ["albef", "vlmo"])
 def test_mixed_schedule_batch_equals_reference_loops(gold, flavor):
-    """Two samples with DIFFERENT schedules (6 substitutable words / none) attacked as ONE batch by ``attack_mixed``
+    """Three samples with DIFFERENT schedules (6 / 0 / 3 substitutable words) attacked as ONE batch by ``attack_mixed``
     (prefix scheduling, per-sample probe steps, acceptance on the device) vs the reference's own per-sample loop runs:
     each sample's adversarial text, image and step count must be what the reference produced for it alone."""
     z, meta = gold
@@ -230,7 +230,7 @@ def test_mixed_schedule_batch_equals_reference_loops(gold, flavor):
     else:
         from vqattack_amd.whitebox.vlmo import VlmoAttackAdapters as Adapters
     cases = [c for c in meta["loop_" + flavor]["cases"] if c["old_alg"] == 1]
-    assert len(cases) == 2 and cases[0]["iter_list"] != cases[1]["iter_list"]
+    assert len(cases) == 3 and len({str(c["iter_list"]) for c in cases}) == 3
     parts = [_case_inputs(z, meta, flavor, c, model) for c in cases]
     length = max(p[3].shape[1] for p in parts)
 
