@@ -245,6 +245,28 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
                       const int64_t* ori_ids, int64_t* cur_ids, int32_t* new_id, int32_t* acc_rank, const float* table,
                       int V, int E, float threshold, vqa_stream_t stream);
 
+/* ---------------------------------------------------------------- white-box attention (fp32, head dimension 64)
+ * o = softmax(scale * q k^T + bias) v  per (batch, head), exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32),
+ * flash-style (the Sq x Sk scores never reach HBM).  The frozen white boxes' `Attention.forward`
+ * (vlmo/modules/multiway_transformer.py:88-118; ALBEF_attack/models/vit.py) is a callee of the attack's hot path.
+ * q (B, H, Sq, 64), k / v (B, H, Sk, 64), o (B, H, Sq, 64) are addressed through element strides
+ * strides[12] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh} (batch, sequence, head; the head
+ * dimension is dense; all multiples of 4, bases 16-byte aligned) -- q, k, v may be views of one packed qkv tensor.
+ * bias (nullable): additive fp32 (relative-position bias and/or -inf key padding), bias_strides[3] = {batch, head, query
+ * row} in elements (batch / head stride may be 0), key stride 1.  lse (B, H, Sq) receives log-sum-exp of the scores. */
+int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, int B, int H,
+                 int Sq, int Sk, const long* strides, const long* bias_strides, float scale, vqa_stream_t stream);
+
+/* Gradients of the above w.r.t. q, k, v given go = d loss / d o (the bias is frozen: no gradient).  Deterministic: one
+ * kernel owns query blocks (dq; it also writes delta (B, H, Sq) = rowsum(go . o), scratch), one owns key blocks (dk,
+ * dv); both recompute the probabilities from lse.  No float atomics: bitwise reproducible.
+ * grad_strides[12] = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} (elements;
+ * dq / dk / dv may be the three slices of one packed (B, S, 3, H, 64) gradient buffer). */
+int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
+                 const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Sq, int Sk,
+                 const long* strides, const long* bias_strides, const long* grad_strides, float scale,
+                 vqa_stream_t stream);
+
 /* ---------------------------------------------------------------- input pipeline
  * Pillow-exact bicubic resize of an 8-bit interleaved image (H, W, C), C <= 4, then ToTensor + Normalize into planar
  * fp32 -- what `transforms.Resize((res, res), interpolation=Image.BICUBIC)`, `ToTensor()`, `Normalize(0.5, 0.5)` do on

@@ -1,0 +1,161 @@
+"""fp32 attention of the frozen white boxes on the gfx950 matrix cores (``csrc/attn.hip``), with autograd.
+
+``attention(q, k, v, bias, scale)``: ``q`` (B, Sq, H, 64), ``k`` / ``v`` (B, Sk, H, 64) -- any strides with a dense head
+dimension, e.g. the three slices of a packed ``qkv`` projection -- and an optional additive ``bias`` broadcastable to
+(B, H, Sq, Sk) with a dense last dimension (relative-position bias and / or ``-inf`` key padding).  Returns
+``softmax(scale * q k^T + bias) v`` as (B, Sq, H, 64) contiguous, so the ``reshape(B, Sq, H * 64)`` that follows in a
+transformer block is free.  The white boxes' ``Attention.forward`` (reference: ``vlmo/modules/multiway_transformer.py:
+88-118``) is a callee of the attack's hot path; this replaces ``F.scaled_dot_product_attention`` there (same math, exact
+fp32 products on ``v_mfma_f32_32x32x2_f32``).  There is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import check, lib, ptr, stream_for
+
+HEAD_DIM = 64
+
+
+def _bshd(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[-1] != HEAD_DIM:
+        raise _hip.HipExtensionError("{} must be a float32 (B, S, H, 64) HIP tensor, got {} {}".format(
+            name, t.dtype, tuple(t.shape)))
+    if t.stride(-1) != 1 or any(s % 4 for s in t.stride()[:-1]) or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _bias_view(bias, b, h, sq, sk):
+    """(tensor kept alive, strides (batch, head, row)) of a bias broadcastable to (B, H, Sq, Sk).
+
+    The kernels read a row in aligned groups of four keys, the last group included, so a row must span ceil4(Sk)
+    floats: a bias whose rows do not (or that is not 16-byte aligned) is copied once, in its own un-broadcast shape,
+    into rows padded to a multiple of 16 floats."""
+    if bias is None:
+        return None, None
+    if bias.dtype != torch.float32 or not bias.is_cuda:
+        raise TypeError("bias must be a float32 HIP tensor")
+    while bias.dim() < 4:
+        bias = bias.unsqueeze(0)
+    if bias.shape[-1] != sk:
+        raise ValueError("bias must have Sk = {} entries in its last dimension, got {}".format(sk, bias.shape[-1]))
+    # broadcast (stride-0) dimensions are collapsed first, so that a copy, if one is needed, stays small
+    bias = bias[tuple(slice(0, 1) if st == 0 else slice(None) for st in bias.stride()[:-1])]
+    lead = [st for st, n in zip(bias.stride()[:-1], bias.shape[:-1]) if n > 1]
+    room = sk % 4 == 0 or (bool(lead) and min(lead) >= (sk + 3) // 4 * 4)
+    if bias.stride(-1) != 1 or not room or any(st % 4 for st in lead) or bias.data_ptr() % 16:
+        pad = (sk + 15) // 16 * 16
+        store = torch.zeros(tuple(bias.shape[:-1]) + (pad,), dtype=torch.float32, device=bias.device)
+        store[..., :sk] = bias
+        bias = store[..., :sk]
+    bias = bias.expand(b, h, sq, sk)
+    return bias, (bias.stride(0), bias.stride(1), bias.stride(2))
+
+
+def _longs(vals):
+    return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
+
+
+def _forward(q, k, v, bias, bstr, scale):
+    b, sq, h, _ = q.shape
+    sk = k.shape[1]
+    o = torch.empty((b, sq, h, HEAD_DIM), dtype=torch.float32, device=q.device)
+    lse = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
+    strides = _longs([q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                      v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
+    with torch.cuda.device(q.device):
+        check(lib().vqa_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(lse), b, h, sq, sk, strides,
+                                 _longs(bstr) if bstr else None, scale, stream_for(q)), "vqa_attn_fwd")
+    return o, lse
+
+
+def _prepare(q, k, v, bias, scale):
+    q, k, v = _bshd(q, "q"), _bshd(k, "k"), _bshd(v, "v")
+    b, sq, h, _ = q.shape
+    sk = k.shape[1]
+    if k.shape != (b, sk, h, HEAD_DIM) or v.shape != k.shape:
+        raise ValueError("q / k / v shape mismatch: {} {} {}".format(tuple(q.shape), tuple(k.shape), tuple(v.shape)))
+    bias, bstr = _bias_view(bias, b, h, sq, sk)
+    return q, k, v, bias, bstr, HEAD_DIM ** -0.5 if scale is None else float(scale)
+
+
+def attention_forward(q, k, v, bias=None, scale=None):
+    """Forward only; returns ``(o (B, Sq, H, 64), lse (B, H, Sq))``."""
+    return _forward(*_prepare(q, k, v, bias, scale))
+
+
+def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale):
+    b, sq, h, _ = q.shape
+    sk = k.shape[1]
+    if go.stride(-1) != 1 or any(s % 4 for s in go.stride()[:-1]) or go.data_ptr() % 16:
+        go = go.contiguous()
+    delta = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
+    strides = _longs([q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                      v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
+    gstr = _longs([go.stride(0), go.stride(1), go.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
+                   dk.stride(0), dk.stride(1), dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2)])
+    with torch.cuda.device(q.device):
+        check(lib().vqa_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(go), ptr(lse), ptr(delta), ptr(dq),
+                                 ptr(dk), ptr(dv), b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr, scale,
+                                 stream_for(q)), "vqa_attn_bwd")
+
+
+class _Attention(torch.autograd.Function):
+    """Separate q, k, v (B, S, H, 64); gradients come back as three contiguous tensors."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, scale):
+        q, k, v, bias_t, bstr, scale = _prepare(q.detach(), k.detach(), v.detach(),
+                                                None if bias is None else bias.detach(), scale)
+        o, lse = _forward(q, k, v, bias_t, bstr, scale)
+        ctx.save_for_backward(q, k, v, o, lse, bias_t)
+        ctx.bstr, ctx.scale = bstr, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o, lse, bias = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
+            torch.empty_like(k, memory_format=torch.contiguous_format), \
+            torch.empty_like(v, memory_format=torch.contiguous_format)
+        _backward(q, k, v, bias, ctx.bstr, o, lse, go, dq, dk, dv, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+class _PackedSelfAttention(torch.autograd.Function):
+    """Packed projection output qkv (B, S, 3, H, 64): the gradient is ONE packed buffer the kernels write in place --
+    no select / stack copies around the attention in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, scale):
+        qkv = qkv.detach()
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        q, k, v, bias_t, bstr, scale = _prepare(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2],
+                                                None if bias is None else bias.detach(), scale)
+        o, lse = _forward(q, k, v, bias_t, bstr, scale)
+        ctx.save_for_backward(qkv, o, lse, bias_t)
+        ctx.bstr, ctx.scale = bstr, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, o, lse, bias = ctx.saved_tensors
+        dqkv = torch.empty_like(qkv)
+        _backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias, ctx.bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
+                  dqkv[:, :, 2], ctx.scale)
+        return dqkv, None, None
+
+
+def attention(q, k, v, bias=None, scale=None):
+    """``softmax(scale * q k^T + bias) v`` with autograd; q (B, Sq, H, 64), k / v (B, Sk, H, 64) -> (B, Sq, H, 64)."""
+    return _Attention.apply(q, k, v, bias, scale)
+
+
+def self_attention_packed(qkv, bias=None, scale=None):
+    """Self-attention on a packed projection output ``qkv`` (B, S, 3, H, 64) -> (B, S, H, 64), with autograd."""
+    if qkv.dim() != 5 or qkv.shape[2] != 3 or qkv.shape[-1] != HEAD_DIM or not qkv.is_cuda or qkv.dtype != torch.float32:
+        raise _hip.HipExtensionError("qkv must be a float32 (B, S, 3, H, 64) HIP tensor")
+    return _PackedSelfAttention.apply(qkv, bias, scale)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip.so")
-SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "ce.hip", "text.hip", "image.hip"]
+SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "ce.hip", "text.hip", "image.hip", "attn.hip"]
 # -ffp-contract=off: the reference's op chain rounds after every add/mul; keep it that way (bit-exact parity).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]

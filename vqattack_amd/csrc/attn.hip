@@ -1,0 +1,564 @@
+// fp32 attention for the frozen white boxes on the CDNA4 matrix cores (gfx950 / MI355X), head dimension 64.
+//
+// The attack's device time is dominated by the white box's forward / backward (SURVEY.md section 2.1 lists
+// `Attention.forward`, vlmo/modules/multiway_transformer.py:88-118, as a callee of the hot path): fp32 attention is
+// 29 % of it.  These kernels compute  softmax(scale * Q K^T + bias) V  and its gradients in exact fp32 on
+// v_mfma_f32_32x32x2_f32 (one rounding per product, fp32 accumulation -- the arithmetic class of the reference's
+// `q.float() @ k.float().transpose(-2, -1)`), flash-style: the S x S scores never reach HBM.
+//
+// MFMA 32x32x2 f32 lane maps (lane l, r = l & 31, h = l >> 5):  A[row r][k = h],  B[k = h][col r],
+// C/D[row = (i & 3) + 8 (i >> 2) + 4 h][col r] for accumulator register i in [0, 16).
+//
+// Forward (one workgroup = 4 waves = 128 queries of one (batch, head); K / V tiles of 32 keys through LDS):
+//   S^T = K . Q^T with the KEY on the accumulator rows and the QUERY on the lane, so that (a) a query's row maximum /
+//   sum is 16 in-register values + one exchange with lane ^ 32, and (b) the accumulator registers ARE the B operand of
+//   the second product  O^T += V^T . P^T  (k-pair of step i = keys r0(i), r0(i) + 4: no LDS round trip for P).
+// Backward, deterministic (no float atomics): one kernel owns key blocks (dK, dV: 4 products per tile), one owns query
+//   blocks (dQ: 3 products per tile); both recompute P from the forward's log-sum-exp; the row constants -LSE and
+//   -delta (delta = rowsum(dO . O)) are loaded into the accumulators before the MFMA chains.
+#include "common.hpp"
+
+namespace vqa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHeadDim = 64;
+constexpr int kTile = 32;               // keys (or queries) per MFMA tile
+constexpr int kKs = 65;                 // LDS row stride for "row on the lane" reads  (bank = (row + col) % 64)
+constexpr int kVs = 72;                 // LDS row stride for "column on the lane" reads of rows r and r + 4
+
+struct AttnDims {
+  int B, H, Sq, Sk;
+  long q_sb, q_ss, q_sh;                // element strides of (batch, sequence, head); the head dimension is dense
+  long k_sb, k_ss, k_sh;
+  long v_sb, v_ss, v_sh;
+  long o_sb, o_ss, o_sh;
+  long bias_sb, bias_sh, bias_sr;       // additive bias (batch, head, query row); key stride 1; batch / head stride may be 0
+  float scale;
+};
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// Cooperative load of a 32 x 64 tile (rows [row0, row0 + 32) of a (seq, 64) matrix with row stride `ss`) into LDS with
+// row stride STRIDE; rows >= n_rows are zero-filled.  256 threads, two 16-byte loads each.
+template <int STRIDE>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ base, long ss, int row0, int n_rows,
+                                           float mul) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x * 2 + j;          // float4 index within the tile
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row0 + row < n_rows) v = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row0 + row) * ss + c4);
+    float* dst = lds + row * STRIDE + c4;
+    if (STRIDE % 4 == 0) {
+      *reinterpret_cast<f32x4*>(dst) = v * mul;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = v[e] * mul;
+    }
+  }
+}
+
+// The same tile in two steps, for software pipelining: the global loads of tile t + 1 are issued into registers before
+// tile t is computed and are written to the OTHER LDS buffer after it, so their latency hides behind ~4000 MFMA cycles
+// and a tile costs one barrier.
+struct TileRegs {
+  f32x4 v[2];
+};
+
+__device__ __forceinline__ TileRegs load_tile(const float* __restrict__ base, long ss, int row0, int n_rows) {
+  TileRegs t;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x * 2 + j;
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    t.v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (row0 + row < n_rows) t.v[j] = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row0 + row) * ss + c4);
+  }
+  return t;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void store_tile(float* lds, const TileRegs& t, float mul) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x * 2 + j;
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    float* dst = lds + row * STRIDE + c4;
+    if (STRIDE % 4 == 0) {
+      *reinterpret_cast<f32x4*>(dst) = t.v[j] * mul;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = t.v[j][e] * mul;
+    }
+  }
+}
+
+// Bias of one query row for the 32 keys of a tile in the S^T accumulator layout: lane half h holds keys
+// k0 + 8 g + 4 h + e (g, e < 4), i.e. four 16-byte loads.  Always issued (no branches, so they overlap the MFMA chain);
+// a group beyond the last key reads the row's last aligned group instead -- rows span at least ceil4(Sk) floats
+// (attention.py pads them) -- and add_bias_mask discards it.
+template <bool HAS_BIAS>
+__device__ __forceinline__ void load_bias_row(f32x4 (&bv)[4], const float* __restrict__ bp, int k0, int h, int Sk) {
+  if (!HAS_BIAS) return;
+  const int last = ((Sk + 3) & ~3) - 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int key = k0 + 8 * g + 4 * h;
+    bv[g] = *reinterpret_cast<const f32x4*>(bp + (key < last ? key : last));
+  }
+}
+
+template <bool HAS_BIAS>
+__device__ __forceinline__ void add_bias_mask(f32x16& st, const f32x4 (&bv)[4], int k0, int h, int Sk) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = k0 + 8 * g + 4 * h + e;
+      const float x = HAS_BIAS ? st[4 * g + e] + bv[g][e] : st[4 * g + e];
+      st[4 * g + e] = key < Sk ? x : -INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v,
+                                                             const float* __restrict__ bias, float* __restrict__ o,
+                                                             float* __restrict__ lse, AttnDims d) {
+  __shared__ float Kbuf[2][kTile * kKs];
+  __shared__ float Vbuf[2][kTile * kVs];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * kTile;
+  const bool active = q0 < d.Sq;                           // a wave past the last query only helps staging the tiles
+  const int qi = q0 + r;                                   // this lane's query
+  const int ql = qi < d.Sq ? qi : d.Sq - 1;                // clamped for loads
+  const float* qp = q + b * d.q_sb + head * d.q_sh + static_cast<long>(ql) * d.q_ss + 32 * h;
+  const float* kb = k + b * d.k_sb + head * d.k_sh;
+  const float* vb = v + b * d.v_sb + head * d.v_sh;
+  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr : nullptr;
+  float qf[32];                                            // Q[query][32 h + s] * scale: the B operand of S^T = K . Q^T
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = t[e] * d.scale;
+  }
+  f32x16 o0 = {0}, o1 = {0};                               // O^T[dim (+32)][query]
+  float m = -INFINITY, l = 0.0f;
+  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  {
+    const TileRegs tk = load_tile(kb, d.k_ss, 0, d.Sk), tv = load_tile(vb, d.v_ss, 0, d.Sk);
+    store_tile<kKs>(Kbuf[0], tk, 1.0f);
+    store_tile<kVs>(Vbuf[0], tv, 1.0f);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int k0 = kt * kTile;
+    const float* Ks = Kbuf[kt & 1];
+    const float* Vs = Vbuf[kt & 1];
+    const bool more = kt + 1 < n_tiles;
+    TileRegs tk, tv;
+    if (more) {                                  // in flight while this tile is computed
+      tk = load_tile(kb, d.k_ss, k0 + kTile, d.Sk);
+      tv = load_tile(vb, d.v_ss, k0 + kTile, d.Sk);
+    }
+    if (active) {
+    f32x4 bv[4];
+    load_bias_row<HAS_BIAS>(bv, bp, k0, h, d.Sk);    // issued ahead of the MFMA chain that hides their latency
+    __builtin_amdgcn_sched_barrier(0);               // ... and kept there: the scheduler would sink them to their use
+    f32x16 st = {0};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) st = mfma(Ks[r * kKs + s + 32 * h], qf[s], st);
+    // st[i] = scale * <q, k_key> for key = k0 + acc_row(i, h); add the bias, mask the keys beyond Sk
+    add_bias_mask<HAS_BIAS>(st, bv, k0, h, d.Sk);
+    float mx = st[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+    const float m_new = fmaxf(m, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;       // a fully masked row so far: exp(-inf - 0) = 0
+    const float alpha = __expf(m - m_use);                          // m = -inf -> 0
+    float rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = __expf(st[i] - m_use);
+      rs += st[i];
+    }
+    rs += __shfl_xor(rs, 32, kWave);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o0[i] *= alpha;
+      o1[i] *= alpha;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                  // O^T += V^T . P^T, k-pair = keys r0(i), r0(i) + 4
+      const int key = acc_row(i, h);
+      o0 = mfma(Vs[key * kVs + r], st[i], o0);
+      o1 = mfma(Vs[key * kVs + 32 + r], st[i], o1);
+    }
+    }
+    if (more) {                                  // the other buffer was last read one tile ago (barrier in between)
+      store_tile<kKs>(Kbuf[(kt + 1) & 1], tk, 1.0f);
+      store_tile<kVs>(Vbuf[(kt + 1) & 1], tv, 1.0f);
+    }
+    __syncthreads();
+  }
+  if (qi < d.Sq) {
+    const float inv = 1.0f / l;
+    float* op = o + b * d.o_sb + head * d.o_sh + static_cast<long>(qi) * d.o_ss;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dim = 8 * g + 4 * h;
+      f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + dim) = a;
+      *reinterpret_cast<f32x4*>(op + 32 + dim) = c;
+    }
+    if (h == 0) lse[(static_cast<long>(b) * d.H + head) * d.Sq + qi] = m + __logf(l);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// One workgroup = 4 waves = 128 queries of one (batch, head); loop over key tiles.  Query on the lane:
+//   S'^T = K . Q^T + bias - LSE (key rows in the accumulator),  P^T = exp(S'^T),  dP^T = V . dO^T - delta,
+//   dS^T = P^T o dP^T,  dQ^T += K^T . dS^T  (sum over the key = the accumulator's row index: registers feed the MFMA).
+// Also computes delta[b, h, q] = sum_d dO . O for its queries and stores it for the dK / dV kernel that follows.
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ o,
+                                                                const float* __restrict__ go,
+                                                                const float* __restrict__ lse,
+                                                                float* __restrict__ delta, float* __restrict__ dq,
+                                                                AttnDims d, long dq_sb, long dq_ss, long dq_sh,
+                                                                long go_sb, long go_ss, long go_sh) {
+  __shared__ float Kbuf[2][kTile * kKs];
+  __shared__ float Vbuf[2][kTile * kKs];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qi = blockIdx.x * 128 + wave * kTile + r;
+  const bool active = blockIdx.x * 128 + wave * kTile < d.Sq;
+  const int ql = qi < d.Sq ? qi : d.Sq - 1;
+  const float* qp = q + b * d.q_sb + head * d.q_sh + static_cast<long>(ql) * d.q_ss + 32 * h;
+  const float* gp = go + b * go_sb + head * go_sh + static_cast<long>(ql) * go_ss + 32 * h;
+  const float* op = o + b * d.o_sb + head * d.o_sh + static_cast<long>(ql) * d.o_ss + 32 * h;
+  const float* kb = k + b * d.k_sb + head * d.k_sh;
+  const float* vb = v + b * d.v_sb + head * d.v_sh;
+  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr : nullptr;
+  const long row = (static_cast<long>(b) * d.H + head) * d.Sq + ql;
+  float qf[32], gf[32];
+  float dl = 0.0f;
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4) {
+    const f32x4 tq = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+    const f32x4 tg = *reinterpret_cast<const f32x4*>(gp + 4 * s4);
+    const f32x4 to = *reinterpret_cast<const f32x4*>(op + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qf[4 * s4 + e] = tq[e] * d.scale;
+      gf[4 * s4 + e] = tg[e];
+      dl += tg[e] * to[e];
+    }
+  }
+  dl += __shfl_xor(dl, 32, kWave);
+  if (h == 0 && qi < d.Sq) delta[row] = dl;
+  const float neg_lse = -lse[row];
+  f32x16 dq0 = {0}, dq1 = {0};
+  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  {
+    const TileRegs tk = load_tile(kb, d.k_ss, 0, d.Sk), tv = load_tile(vb, d.v_ss, 0, d.Sk);
+    store_tile<kKs>(Kbuf[0], tk, 1.0f);
+    store_tile<kKs>(Vbuf[0], tv, 1.0f);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int k0 = kt * kTile;
+    const float* Ks = Kbuf[kt & 1];
+    const float* Vs = Vbuf[kt & 1];
+    const bool more = kt + 1 < n_tiles;
+    TileRegs tk, tv;
+    if (more) {
+      tk = load_tile(kb, d.k_ss, k0 + kTile, d.Sk);
+      tv = load_tile(vb, d.v_ss, k0 + kTile, d.Sk);
+    }
+    if (active) {
+    f32x16 st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = neg_lse;
+      dp[i] = -dl;
+    }
+    f32x4 bv[4];
+    load_bias_row<HAS_BIAS>(bv, bp, k0, h, d.Sk);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      st = mfma(Ks[r * kKs + s + 32 * h], qf[s], st);
+      dp = mfma(Vs[r * kKs + s + 32 * h], gf[s], dp);
+    }
+    add_bias_mask<HAS_BIAS>(st, bv, k0, h, d.Sk);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = __expf(st[i]) * dp[i];          // dS^T = P^T o (dP^T - delta)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = acc_row(i, h);
+      dq0 = mfma(Ks[key * kKs + r], st[i], dq0);
+      dq1 = mfma(Ks[key * kKs + 32 + r], st[i], dq1);
+    }
+    }
+    if (more) {
+      store_tile<kKs>(Kbuf[(kt + 1) & 1], tk, 1.0f);
+      store_tile<kKs>(Vbuf[(kt + 1) & 1], tv, 1.0f);
+    }
+    __syncthreads();
+  }
+  if (qi < d.Sq) {
+    float* dp_ = dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dim = 8 * g + 4 * h;
+      f32x4 a = {dq0[4 * g] * d.scale, dq0[4 * g + 1] * d.scale, dq0[4 * g + 2] * d.scale, dq0[4 * g + 3] * d.scale};
+      f32x4 c = {dq1[4 * g] * d.scale, dq1[4 * g + 1] * d.scale, dq1[4 * g + 2] * d.scale, dq1[4 * g + 3] * d.scale};
+      *reinterpret_cast<f32x4*>(dp_ + dim) = a;
+      *reinterpret_cast<f32x4*>(dp_ + 32 + dim) = c;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// One workgroup = 4 waves = 128 keys of one (batch, head); loop over query tiles of 32.  Key on the lane:
+//   S' = Q . K^T + bias - LSE (query rows in the accumulator),  P = exp(S'),  dP = dO . V^T - delta,  dS = P o dP,
+//   dV^T += dO^T . P,  dK^T += (scale Q)^T . dS   (both sum over the query = the accumulators' row index).
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
+                                                                 const float* __restrict__ k,
+                                                                 const float* __restrict__ v,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ go,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 float* __restrict__ dk, float* __restrict__ dv,
+                                                                 AttnDims d, long dk_sb, long dk_ss, long dk_sh,
+                                                                 long dv_sb, long dv_ss, long dv_sh, long go_sb,
+                                                                 long go_ss, long go_sh) {
+  __shared__ float Qbuf[2][kTile * kKs];
+  __shared__ float Gbuf[2][kTile * kKs];
+  __shared__ float Lbuf[2][kTile], Dbuf[2][kTile];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int ki = blockIdx.x * 128 + wave * kTile + r;                 // this lane's key
+  const bool active = blockIdx.x * 128 + wave * kTile < d.Sk;
+  const int kl = ki < d.Sk ? ki : d.Sk - 1;
+  const float* kp = k + b * d.k_sb + head * d.k_sh + static_cast<long>(kl) * d.k_ss + 32 * h;
+  const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
+  const float* qb = q + b * d.q_sb + head * d.q_sh;
+  const float* gb = go + b * go_sb + head * go_sh;
+  const float* bb = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + kl : nullptr;
+  const long rows = (static_cast<long>(b) * d.H + head) * d.Sq;
+  float kf[32], vf[32];
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4) {
+    const f32x4 tk = *reinterpret_cast<const f32x4*>(kp + 4 * s4);
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(vp + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kf[4 * s4 + e] = tk[e];
+      vf[4 * s4 + e] = tv[e];
+    }
+  }
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int n_tiles = (d.Sq + kTile - 1) / kTile;
+  // per-query row constants of a tile: thread t < 32 carries (lse, delta) of query q0 + t
+  auto row_consts = [&](int q0, float& rl, float& rd) {
+    const int qq = q0 + static_cast<int>(threadIdx.x);
+    const bool ok = threadIdx.x < kTile && qq < d.Sq;
+    rl = ok ? lse[rows + qq] : INFINITY;                             // a query beyond Sq: P = exp(-inf) = 0
+    rd = ok ? delta[rows + qq] : 0.0f;
+  };
+  {
+    const TileRegs tq = load_tile(qb, d.q_ss, 0, d.Sq), tg = load_tile(gb, go_ss, 0, d.Sq);
+    float rl, rd;
+    row_consts(0, rl, rd);
+    store_tile<kKs>(Qbuf[0], tq, d.scale);
+    store_tile<kKs>(Gbuf[0], tg, 1.0f);
+    if (threadIdx.x < kTile) {
+      Lbuf[0][threadIdx.x] = rl;
+      Dbuf[0][threadIdx.x] = rd;
+    }
+  }
+  __syncthreads();
+  for (int qt = 0; qt < n_tiles; ++qt) {
+    const int q0 = qt * kTile;
+    const float* Qs = Qbuf[qt & 1];
+    const float* Gs = Gbuf[qt & 1];
+    const float* Ls = Lbuf[qt & 1];
+    const float* Ds = Dbuf[qt & 1];
+    const bool more = qt + 1 < n_tiles;
+    TileRegs tq, tg;
+    float rl = 0.0f, rd = 0.0f;
+    if (more) {
+      tq = load_tile(qb, d.q_ss, q0 + kTile, d.Sq);
+      tg = load_tile(gb, go_ss, q0 + kTile, d.Sq);
+      row_consts(q0 + kTile, rl, rd);
+    }
+    if (active) {
+    f32x16 st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qr = acc_row(i, h);
+      st[i] = -Ls[qr];
+      dp[i] = -Ds[qr];
+    }
+    float bv[16];
+    if (HAS_BIAS) {                              // this key's bias for the tile's 16 query rows of this lane half
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = q0 + acc_row(i, h);
+        bv[i] = bb[static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * d.bias_sr];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      st = mfma(Qs[r * kKs + s + 32 * h], kf[s], st);
+      dp = mfma(Gs[r * kKs + s + 32 * h], vf[s], dp);
+    }
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] += bv[i];   // a query beyond Sq already has st = -inf
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = __expf(st[i]);                     // P
+      dp[i] = st[i] * dp[i];                     // dS
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qr = acc_row(i, h);
+      dv0 = mfma(Gs[qr * kKs + r], st[i], dv0);
+      dv1 = mfma(Gs[qr * kKs + 32 + r], st[i], dv1);
+      dk0 = mfma(Qs[qr * kKs + r], dp[i], dk0);
+      dk1 = mfma(Qs[qr * kKs + 32 + r], dp[i], dk1);
+    }
+    }
+    if (more) {
+      store_tile<kKs>(Qbuf[(qt + 1) & 1], tq, d.scale);
+      store_tile<kKs>(Gbuf[(qt + 1) & 1], tg, 1.0f);
+      if (threadIdx.x < kTile) {
+        Lbuf[(qt + 1) & 1][threadIdx.x] = rl;
+        Dbuf[(qt + 1) & 1][threadIdx.x] = rd;
+      }
+    }
+    __syncthreads();
+  }
+  if (ki < d.Sk) {
+    float* pk = dk + b * dk_sb + head * dk_sh + static_cast<long>(ki) * dk_ss;
+    float* pv = dv + b * dv_sb + head * dv_sh + static_cast<long>(ki) * dv_ss;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dim = 8 * g + 4 * h;
+      *reinterpret_cast<f32x4*>(pk + dim) = f32x4{dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(pk + 32 + dim) = f32x4{dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(pv + dim) = f32x4{dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(pv + 32 + dim) = f32x4{dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]};
+    }
+  }
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" {
+
+static int check_attn(const float* q, const float* k, const float* v, const AttnDims& d) {
+  if (!q || !k || !v) return VQA_ERR_NULL;
+  if (d.B < 0 || d.H <= 0 || d.Sq <= 0 || d.Sk <= 0 || d.H > 65535 || d.B > 65535) return VQA_ERR_SHAPE;
+  if ((d.q_sb | d.q_ss | d.q_sh | d.k_sb | d.k_ss | d.k_sh | d.v_sb | d.v_ss | d.v_sh | d.o_sb | d.o_ss | d.o_sh) & 3)
+    return VQA_ERR_SHAPE;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v)) return VQA_ERR_ALIGN;
+  return VQA_OK;
+}
+
+/* strides: 12 longs = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh}; bias_strides: 3 longs */
+int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, int B, int H,
+                 int Sq, int Sk, const long* strides, const long* bias_strides, float scale, vqa_stream_t stream) {
+  clear_stale_error();
+  if (!strides || !o || !lse || (bias && !bias_strides)) return VQA_ERR_NULL;
+  AttnDims d{B, H, Sq, Sk, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], strides[6],
+             strides[7], strides[8], strides[9], strides[10], strides[11], 0, 0, 0, scale};
+  if (bias) {
+    d.bias_sb = bias_strides[0];
+    d.bias_sh = bias_strides[1];
+    d.bias_sr = bias_strides[2];
+    if (((d.bias_sb | d.bias_sh | d.bias_sr) & 3) || !aligned16(bias)) return VQA_ERR_ALIGN;
+  }
+  const int rc = check_attn(q, k, v, d);
+  if (rc != VQA_OK) return rc;
+  if (!aligned16(o)) return VQA_ERR_ALIGN;
+  if (B == 0) return VQA_OK;
+  dim3 grid((Sq + 127) / 128, H, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bias) attn_fwd_kernel<true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
+  else attn_fwd_kernel<false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
+  return launch_status();
+}
+
+/* grad_strides: 12 longs = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} */
+int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
+                 const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Sq, int Sk,
+                 const long* strides, const long* bias_strides, const long* grad_strides, float scale,
+                 vqa_stream_t stream) {
+  clear_stale_error();
+  if (!strides || !grad_strides || !o || !go || !lse || !delta || !dq || !dk || !dv || (bias && !bias_strides))
+    return VQA_ERR_NULL;
+  AttnDims d{B, H, Sq, Sk, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], strides[6],
+             strides[7], strides[8], strides[9], strides[10], strides[11], 0, 0, 0, scale};
+  if (bias) {
+    d.bias_sb = bias_strides[0];
+    d.bias_sh = bias_strides[1];
+    d.bias_sr = bias_strides[2];
+    if (((d.bias_sb | d.bias_sh | d.bias_sr) & 3) || !aligned16(bias)) return VQA_ERR_ALIGN;
+  }
+  const int rc = check_attn(q, k, v, d);
+  if (rc != VQA_OK) return rc;
+  long any = 0;
+  for (int i = 0; i < 12; ++i) any |= grad_strides[i];
+  if (any & 3) return VQA_ERR_SHAPE;
+  if (!aligned16(o) || !aligned16(go) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv)) return VQA_ERR_ALIGN;
+  if (B == 0) return VQA_OK;
+  const long* g = grad_strides;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 gq((Sq + 127) / 128, H, B), gk((Sk + 127) / 128, H, B);
+  if (bias) {
+    attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
+                                                     g[2]);
+    attn_bwd_dkv_kernel<true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8], g[9],
+                                                      g[10], g[11], g[0], g[1], g[2]);
+  } else {
+    attn_bwd_dq_kernel<false><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0],
+                                                      g[1], g[2]);
+    attn_bwd_dkv_kernel<false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8], g[9],
+                                                       g[10], g[11], g[0], g[1], g[2]);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..features import LayerFeatures
+from ._mha import mha
 
 
 @dataclass
@@ -79,11 +80,9 @@ class _MHA(nn.Module):
         b, n, c = x.shape
         m = ctx.shape[1]
         h = self.heads
-        q = self.q(x).reshape(b, n, h, c // h).transpose(1, 2)
-        k = self.k(ctx).reshape(b, m, h, c // h).transpose(1, 2)
-        v = self.v(ctx).reshape(b, m, h, c // h).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.o(o.transpose(1, 2).reshape(b, n, c))
+        o = mha(self.q(x).reshape(b, n, h, c // h), self.k(ctx).reshape(b, m, h, c // h),
+                self.v(ctx).reshape(b, m, h, c // h), mask)
+        return self.o(o.reshape(b, n, c))
 
 
 class _VitBlock(nn.Module):

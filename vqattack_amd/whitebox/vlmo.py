@@ -12,8 +12,8 @@ Differences from the reference that serve the MI355X design (none changes a sing
   * per-layer features are returned as ``LayerFeatures`` (no ``torch.stack`` copy, SURVEY.md 8f rank 1);
   * the patch embedding is an unfold + GEMM (``F.linear``) instead of a strided ``Conv2d``: its backward w.r.t. the
     image -- the producer of the gradient the fused step kernel consumes -- is then a plain GEMM;
-  * attention goes through ``F.scaled_dot_product_attention`` with the relative-position bias and key-padding mask
-    folded into one additive mask.
+  * attention is the exact-fp32 MFMA kernel of ``csrc/attn.hip`` (``_mha.py``) on the packed qkv projection, with the
+    relative-position bias and key-padding mask folded into one additive mask.
 """
 from dataclasses import dataclass
 
@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..features import LayerFeatures
+from ._mha import mha_packed
 
 
 @dataclass
@@ -87,9 +88,8 @@ class Attention(nn.Module):
 
     def forward(self, x, bias):
         b, n, c = x.shape
-        qkv = self.qkv(x).reshape(b, n, 3, self.heads, c // self.heads).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias)
-        return self.proj(o.transpose(1, 2).reshape(b, n, c))
+        o = mha_packed(self.qkv(x).reshape(b, n, 3, self.heads, c // self.heads), bias)
+        return self.proj(o.reshape(b, n, c))
 
 
 class Block(nn.Module):
@@ -230,8 +230,8 @@ class FrozenVlmo(nn.Module):
         gathered for the kept positions only -- a masked key contributes exp(-inf) = 0 to every softmax, so dropping
         it changes no result.  The masks depend only on the text batch, so an attack builds them ONCE per text batch
         and reuses them for every PGD step.  Layout choices that keep the fused attention kernel off the HBM roof:
-          * rows are padded to a multiple of 16 floats in storage and sliced back, so SDPA's alignment check passes
-            and it does not re-pad (= copy) the whole mask on every call;
+          * rows are padded to a multiple of 16 floats in storage and sliced back: the attention kernels read a row
+            in aligned 16-byte groups, and neither they nor the library re-pad (= copy) the mask on every call;
           * when every question of the batch has the same padding pattern (batches are bucketed by schedule and
             length) the mask is ONE (1, heads, S, S) slab expanded over the batch with stride 0: 18 MB per layer that
             stays cache-resident instead of a (B, heads, S, S) tensor (1.17 GB at batch 64) streamed by every
