@@ -253,7 +253,9 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
  * strides[12] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh} (batch, sequence, head; the head
  * dimension is dense; all multiples of 4, bases 16-byte aligned) -- q, k, v may be views of one packed qkv tensor.
  * bias (nullable): additive fp32 (relative-position bias and/or -inf key padding), bias_strides[3] = {batch, head, query
- * row} in elements (batch / head stride may be 0), key stride 1.  lse (B, H, Sq) receives log-sum-exp of the scores. */
+ * row} in elements (batch / head stride may be 0, all multiples of 4), key stride 1.  The kernels read bias rows in
+ * whole tiles of 32 keys: from every row start, ceil32(Sk) floats must be readable (pad the rows; what lies beyond Sk
+ * is masked, never used).  lse (B, H, Sq) receives log-sum-exp of the scores. */
 int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, int B, int H,
                  int Sq, int Sk, const long* strides, const long* bias_strides, float scale, vqa_stream_t stream);
 

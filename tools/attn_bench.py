@@ -29,10 +29,10 @@ def timeit(fn, reps=10):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(B, S, 3, H, D, device="cuda", generator=g)
-    spad = (S + 15) // 16 * 16
+    spad = (S + 31) // 32 * 32
     store = torch.zeros(1, H, S, spad, device="cuda")
     store[..., :S] = torch.randn(1, H, S, S, device="cuda", generator=g) * 0.02
-    bias = store[..., :S].expand(B, -1, -1, -1)
+    bias = store[..., :S].expand(B, -1, -1, -1) if os.environ.get("BIAS", "1") == "1" else None
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     flops_fwd = 4.0 * B * H * S * S * D
     ms = timeit(lambda: attention.attention_forward(q, k, v, bias))
@@ -61,7 +61,7 @@ def main():
                               TFLOPs=round(3.5 * flops_fwd / ms / 1e9, 1))), flush=True)
         o, lse = attention.attention_forward(q, k, v, bias)
         dqkv = torch.empty_like(qkv)
-        bstr = (bias.stride(0), bias.stride(1), bias.stride(2))
+        bstr = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else None
         ms = timeit(lambda: attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
                                                 dqkv[:, :, 2], D ** -0.5))
         print(json.dumps(dict(what="hip bwd kernels", ms=round(ms, 3), TFLOPs=round(2.5 * flops_fwd / ms / 1e9, 1))),

@@ -30,9 +30,11 @@ def _bshd(t, name):
 def _bias_view(bias, b, h, sq, sk):
     """(tensor kept alive, strides (batch, head, row)) of a bias broadcastable to (B, H, Sq, Sk).
 
-    The kernels read a row in aligned groups of four keys, the last group included, so a row must span ceil4(Sk)
-    floats: a bias whose rows do not (or that is not 16-byte aligned) is copied once, in its own un-broadcast shape,
-    into rows padded to a multiple of 16 floats."""
+    The kernels read a bias row in whole tiles of 32 keys with 16-byte loads, the last, partial tile included (what
+    lies beyond Sk is masked, not used): from every row start, ceil32(Sk) floats must be readable.  A bias whose
+    storage does not guarantee that -- or that is not 16-byte aligned -- is copied once, in its own un-broadcast shape,
+    into rows padded to a multiple of 32 floats; producers that build their bias that way (``FrozenVlmo.attention_bias``)
+    are used in place."""
     if bias is None:
         return None, None
     if bias.dtype != torch.float32 or not bias.is_cuda:
@@ -43,10 +45,11 @@ def _bias_view(bias, b, h, sq, sk):
         raise ValueError("bias must have Sk = {} entries in its last dimension, got {}".format(sk, bias.shape[-1]))
     # broadcast (stride-0) dimensions are collapsed first, so that a copy, if one is needed, stays small
     bias = bias[tuple(slice(0, 1) if st == 0 else slice(None) for st in bias.stride()[:-1])]
+    pad = (sk + 31) // 32 * 32
+    last_row = bias.storage_offset() + sum((n - 1) * st for n, st in zip(bias.shape[:-1], bias.stride()[:-1]))
+    room = last_row + pad <= bias.untyped_storage().nbytes() // 4
     lead = [st for st, n in zip(bias.stride()[:-1], bias.shape[:-1]) if n > 1]
-    room = sk % 4 == 0 or (bool(lead) and min(lead) >= (sk + 3) // 4 * 4)
-    if bias.stride(-1) != 1 or not room or any(st % 4 for st in lead) or bias.data_ptr() % 16:
-        pad = (sk + 15) // 16 * 16
+    if bias.stride(-1) != 1 or not room or any(st % 4 or st < 0 for st in lead) or bias.data_ptr() % 16:
         store = torch.zeros(tuple(bias.shape[:-1]) + (pad,), dtype=torch.float32, device=bias.device)
         store[..., :sk] = bias
         bias = store[..., :sk]

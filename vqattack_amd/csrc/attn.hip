@@ -129,13 +129,81 @@ __device__ __forceinline__ void add_bias_mask(f32x16& st, const f32x4 (&bv)[4], 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// On a CDNA4 SIMD vector instructions do not overlap the matrix pipe (tools/mfma_probe.hip: the tile loop's MFMAs alone
+// run at 65 cycles each, and every VALU instruction between them adds its own issue time, whatever the occupancy), so
+// the loop is written to need few of them per 64 MFMAs:
+//   * the bias tile is the INITIAL accumulator of the S^T chain (prefetched one tile ahead), not 16 adds after it;
+//   * exp(s - m) is v_exp_f32(fma(s, log2 e, -m log2 e)): one fma per element, no separate subtract / scale;
+//   * the running maximum is updated lazily, only for rows whose new maximum exceeds it by more than kLazyMax (the
+//     accumulators then hold values up to e^kLazyMax times larger, harmless in fp32): in steady state the 32-register
+//     rescale of O and its exp are skipped by a wave-uniform branch; the decision is per query row, so a row's result
+//     does not depend on its neighbours in the wave;
+//   * the two lane halves keep partial row sums and exchange them once, after the loop (v_permlane32_swap);
+//   * keys beyond Sk are masked in the last tile only; tile rows beyond the sequence are clamped, not zero-filled;
+//   * V sits in LDS with dimensions d and d + 32 interleaved, so one ds_read_b64 with an immediate offset feeds both
+//     P.V products of a key and no address arithmetic is left in the loop.
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kLazyMax = 8.0f;
+constexpr int kVi = 66;                 // LDS row stride of the interleaved V tile: conflict-free stores and b64 reads
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Value of the same lane index in the other half of the wave, combined: max / sum over lanes l and l ^ 32.
+__device__ __forceinline__ float halves_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// 32 x 64 tile -> registers, rows clamped to the last valid one (their products are masked or multiplied by P = 0).
+__device__ __forceinline__ TileRegs load_tile_clamped(const float* __restrict__ base, long ss, int row0, int n_rows) {
+  TileRegs t;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x * 2 + j;
+    int row = row0 + (idx >> 4);
+    row = row < n_rows ? row : n_rows - 1;
+    t.v[j] = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row) * ss + (idx & 15) * 4);
+  }
+  return t;
+}
+
+// registers -> LDS, dimensions d and d + 32 of a row next to each other
+__device__ __forceinline__ void store_tile_interleaved(float* lds, const TileRegs& t, float mul) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x * 2 + j;
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    float* dst = lds + row * kVi + 2 * (c4 & 31) + (c4 >> 5);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[2 * e] = t.v[j][e] * mul;
+  }
+}
+
+// Bias of this lane's query row for the 32 keys of a tile, in the S^T accumulator layout (register 4 g + e = key
+// k0 + 8 g + 4 h + e).  Rows are readable up to ceil32(Sk) floats (the caller's contract), so no clamping.
+__device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ row, int k0) {
+  f32x16 b;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(row + k0 + 8 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[4 * g + e] = t[e];
+  }
+  return b;
+}
+
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v,
                                                              const float* __restrict__ bias, float* __restrict__ o,
                                                              float* __restrict__ lse, AttnDims d) {
   __shared__ float Kbuf[2][kTile * kKs];
-  __shared__ float Vbuf[2][kTile * kVs];
+  __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
@@ -146,7 +214,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   const float* qp = q + b * d.q_sb + head * d.q_sh + static_cast<long>(ql) * d.q_ss + 32 * h;
   const float* kb = k + b * d.k_sb + head * d.k_sh;
   const float* vb = v + b * d.v_sb + head * d.v_sh;
-  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr : nullptr;
+  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr + 4 * h
+                             : nullptr;
   float qf[32];                                            // Q[query][32 h + s] * scale: the B operand of S^T = K . Q^T
 #pragma unroll
   for (int s4 = 0; s4 < 8; ++s4) {
@@ -155,68 +224,76 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
     for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = t[e] * d.scale;
   }
   f32x16 o0 = {0}, o1 = {0};                               // O^T[dim (+32)][query]
-  float m = -INFINITY, l = 0.0f;
+  float m = -INFINITY, mc = 0.0f, l = 0.0f;                // running max, the same times log2 e (0 while -inf), row sum
   const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  f32x16 bcur = {0};
+  if (HAS_BIAS && active) bcur = load_bias_tile(bp, 0);
   {
-    const TileRegs tk = load_tile(kb, d.k_ss, 0, d.Sk), tv = load_tile(vb, d.v_ss, 0, d.Sk);
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk), tv = load_tile_clamped(vb, d.v_ss, 0, d.Sk);
     store_tile<kKs>(Kbuf[0], tk, 1.0f);
-    store_tile<kVs>(Vbuf[0], tv, 1.0f);
+    store_tile_interleaved(Vbuf[0], tv, 1.0f);
   }
   __syncthreads();
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int k0 = kt * kTile;
-    const float* Ks = Kbuf[kt & 1];
-    const float* Vs = Vbuf[kt & 1];
+    const float* Ks = Kbuf[kt & 1] + r * kKs + 32 * h;
+    const float* Vs = Vbuf[kt & 1] + 4 * h * kVi + 2 * r;
     const bool more = kt + 1 < n_tiles;
     TileRegs tk, tv;
     if (more) {                                  // in flight while this tile is computed
-      tk = load_tile(kb, d.k_ss, k0 + kTile, d.Sk);
-      tv = load_tile(vb, d.v_ss, k0 + kTile, d.Sk);
+      tk = load_tile_clamped(kb, d.k_ss, k0 + kTile, d.Sk);
+      tv = load_tile_clamped(vb, d.v_ss, k0 + kTile, d.Sk);
     }
     if (active) {
-    f32x4 bv[4];
-    load_bias_row<HAS_BIAS>(bv, bp, k0, h, d.Sk);    // issued ahead of the MFMA chain that hides their latency
-    __builtin_amdgcn_sched_barrier(0);               // ... and kept there: the scheduler would sink them to their use
-    f32x16 st = {0};
+      f32x16 bnext = {0};
+      if (HAS_BIAS && more) bnext = load_bias_tile(bp, k0 + kTile);
+      __builtin_amdgcn_sched_barrier(0);         // keep every load ahead of the MFMA chain that hides its latency
+      f32x16 st = bcur;                          // S^T = bias + K . (scale Q)^T, key on the accumulator row
 #pragma unroll
-    for (int s = 0; s < 32; ++s) st = mfma(Ks[r * kKs + s + 32 * h], qf[s], st);
-    // st[i] = scale * <q, k_key> for key = k0 + acc_row(i, h); add the bias, mask the keys beyond Sk
-    add_bias_mask<HAS_BIAS>(st, bv, k0, h, d.Sk);
-    float mx = st[0];
+      for (int s = 0; s < 32; ++s) st = mfma(Ks[s], qf[s], st);
+      if (k0 + kTile > d.Sk) {                   // last, partial tile: keys beyond Sk never win the softmax
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-    const float m_new = fmaxf(m, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;       // a fully masked row so far: exp(-inf - 0) = 0
-    const float alpha = __expf(m - m_use);                          // m = -inf -> 0
-    float rs = 0.0f;
+        for (int i = 0; i < 16; ++i) st[i] = k0 + acc_row(i, h) < d.Sk ? st[i] : -INFINITY;
+      }
+      float mx = st[0];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      st[i] = __expf(st[i] - m_use);
-      rs += st[i];
-    }
-    rs += __shfl_xor(rs, 32, kWave);
-    l = l * alpha + rs;
-    m = m_new;
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
+      mx = halves_max(mx);
+      const bool grow = mx > m + kLazyMax;       // m = -inf: any finite score starts the row
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+        const float m_new = grow ? mx : m;
+        const float mc_new = m_new * kLog2e;     // m_new is finite wherever it changed
+        const float alpha = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mc - mc_new);   // exactly 1 if unchanged
+        m = m_new;
+        mc = grow ? mc_new : mc;
+        l *= alpha;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      o0[i] *= alpha;
-      o1[i] *= alpha;
-    }
+        for (int i = 0; i < 16; ++i) {
+          o0[i] *= alpha;
+          o1[i] *= alpha;
+        }
+      }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {                                  // O^T += V^T . P^T, k-pair = keys r0(i), r0(i) + 4
-      const int key = acc_row(i, h);
-      o0 = mfma(Vs[key * kVs + r], st[i], o0);
-      o1 = mfma(Vs[key * kVs + 32 + r], st[i], o1);
-    }
+      for (int i = 0; i < 16; ++i) {
+        st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -mc));
+        l += st[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {             // O^T += V^T . P^T, k-pair of step i = keys r0(i), r0(i) + 4
+        const f32x2 vv = *reinterpret_cast<const f32x2*>(Vs + ((i & 3) + 8 * (i >> 2)) * kVi);
+        o0 = mfma(vv[0], st[i], o0);
+        o1 = mfma(vv[1], st[i], o1);
+      }
+      bcur = bnext;
     }
     if (more) {                                  // the other buffer was last read one tile ago (barrier in between)
       store_tile<kKs>(Kbuf[(kt + 1) & 1], tk, 1.0f);
-      store_tile<kVs>(Vbuf[(kt + 1) & 1], tv, 1.0f);
+      store_tile_interleaved(Vbuf[(kt + 1) & 1], tv, 1.0f);
     }
     __syncthreads();
   }
   if (qi < d.Sq) {
+    l = halves_sum(l);
     const float inv = 1.0f / l;
     float* op = o + b * d.o_sb + head * d.o_sh + static_cast<long>(qi) * d.o_ss;
 #pragma unroll
@@ -227,18 +304,21 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
       *reinterpret_cast<f32x4*>(op + dim) = a;
       *reinterpret_cast<f32x4*>(op + 32 + dim) = c;
     }
-    if (h == 0) lse[(static_cast<long>(b) * d.H + head) * d.Sq + qi] = m + __logf(l);
+    if (h == 0) lse[(static_cast<long>(b) * d.H + head) * d.Sq + qi] = mc * kLn2 + __logf(l);
   }
 }
 
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // One workgroup = 4 waves = 128 queries of one (batch, head); loop over key tiles.  Query on the lane:
-//   S'^T = K . Q^T + bias - LSE (key rows in the accumulator),  P^T = exp(S'^T),  dP^T = V . dO^T - delta,
-//   dS^T = P^T o dP^T,  dQ^T += K^T . dS^T  (sum over the key = the accumulator's row index: registers feed the MFMA).
-// Also computes delta[b, h, q] = sum_d dO . O for its queries and stores it for the dK / dV kernel that follows.
+//   S^T = bias + K . (scale Q)^T (key rows in the accumulator),  P^T = exp(S^T - LSE),  dP^T = V . dO^T,
+//   dS^T = P^T o (dP^T - delta),  dQ^T += K^T . dS^T  (sum over the key = the accumulator's row index: registers feed
+//   the MFMA).  Also computes delta[b, h, q] = sum_d dO . O for its queries and stores it for the dK / dV kernel.
+// Same instruction diet as the forward: bias tile = initial accumulator, exp through one fma, packed subtract /
+// multiply for dS, masks in the last tile only.  K and V tiles are interleaved in LDS (dimensions d, d + 32 adjacent):
+// the row reads of the first two products use immediate offsets 2 s, the column reads of the third are one ds_read_b64.
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ o,
@@ -247,8 +327,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __r
                                                                 float* __restrict__ delta, float* __restrict__ dq,
                                                                 AttnDims d, long dq_sb, long dq_ss, long dq_sh,
                                                                 long go_sb, long go_ss, long go_sh) {
-  __shared__ float Kbuf[2][kTile * kKs];
-  __shared__ float Vbuf[2][kTile * kKs];
+  __shared__ __attribute__((aligned(16))) float Kbuf[2][kTile * kVi];
+  __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
@@ -260,7 +340,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __r
   const float* op = o + b * d.o_sb + head * d.o_sh + static_cast<long>(ql) * d.o_ss + 32 * h;
   const float* kb = k + b * d.k_sb + head * d.k_sh;
   const float* vb = v + b * d.v_sb + head * d.v_sh;
-  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr : nullptr;
+  const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr + 4 * h
+                             : nullptr;
   const long row = (static_cast<long>(b) * d.H + head) * d.Sq + ql;
   float qf[32], gf[32];
   float dl = 0.0f;
@@ -276,55 +357,53 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __r
       dl += tg[e] * to[e];
     }
   }
-  dl += __shfl_xor(dl, 32, kWave);
+  dl = halves_sum(dl);
   if (h == 0 && qi < d.Sq) delta[row] = dl;
-  const float neg_lse = -lse[row];
+  const float nlc = -lse[row] * kLog2e;                    // P = exp2(S log2 e - LSE log2 e)
   f32x16 dq0 = {0}, dq1 = {0};
   const int n_tiles = (d.Sk + kTile - 1) / kTile;
   {
-    const TileRegs tk = load_tile(kb, d.k_ss, 0, d.Sk), tv = load_tile(vb, d.v_ss, 0, d.Sk);
-    store_tile<kKs>(Kbuf[0], tk, 1.0f);
-    store_tile<kKs>(Vbuf[0], tv, 1.0f);
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk), tv = load_tile_clamped(vb, d.v_ss, 0, d.Sk);
+    store_tile_interleaved(Kbuf[0], tk, 1.0f);
+    store_tile_interleaved(Vbuf[0], tv, 1.0f);
   }
   __syncthreads();
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int k0 = kt * kTile;
-    const float* Ks = Kbuf[kt & 1];
-    const float* Vs = Vbuf[kt & 1];
+    const float* Kr = Kbuf[kt & 1] + r * kVi + h;          // row read: K[key r][32 h + s] at Kr[2 s]
+    const float* Vr = Vbuf[kt & 1] + r * kVi + h;
+    const float* Kc = Kbuf[kt & 1] + 4 * h * kVi + 2 * r;  // column read: K[key][r], K[key][r + 32]
     const bool more = kt + 1 < n_tiles;
     TileRegs tk, tv;
     if (more) {
-      tk = load_tile(kb, d.k_ss, k0 + kTile, d.Sk);
-      tv = load_tile(vb, d.v_ss, k0 + kTile, d.Sk);
+      tk = load_tile_clamped(kb, d.k_ss, k0 + kTile, d.Sk);
+      tv = load_tile_clamped(vb, d.v_ss, k0 + kTile, d.Sk);
     }
     if (active) {
-    f32x16 st, dp;
+      f32x16 st = {0}, dp = {0};
+      if (HAS_BIAS) st = load_bias_tile(bp, k0);   // the initial accumulator of the S^T chain ...
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      st[i] = neg_lse;
-      dp[i] = -dl;
-    }
-    f32x4 bv[4];
-    load_bias_row<HAS_BIAS>(bv, bp, k0, h, d.Sk);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 32; ++s) dp = mfma(Vr[2 * s], gf[s], dp);   // ... which starts 32 MFMAs after its loads
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      st = mfma(Ks[r * kKs + s + 32 * h], qf[s], st);
-      dp = mfma(Vs[r * kKs + s + 32 * h], gf[s], dp);
-    }
-    add_bias_mask<HAS_BIAS>(st, bv, k0, h, d.Sk);
+      for (int s = 0; s < 32; ++s) st = mfma(Kr[2 * s], qf[s], st);
+      if (k0 + kTile > d.Sk) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st[i] = __expf(st[i]) * dp[i];          // dS^T = P^T o (dP^T - delta)
+        for (int i = 0; i < 16; ++i) st[i] = k0 + acc_row(i, h) < d.Sk ? st[i] : -INFINITY;
+      }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key = acc_row(i, h);
-      dq0 = mfma(Ks[key * kKs + r], st[i], dq0);
-      dq1 = mfma(Ks[key * kKs + 32 + r], st[i], dq1);
-    }
+      for (int i = 0; i < 16; ++i)                 // dS^T = P^T o (dP^T - delta)
+        st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, nlc)) * (dp[i] - dl);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x2 kk = *reinterpret_cast<const f32x2*>(Kc + ((i & 3) + 8 * (i >> 2)) * kVi);
+        dq0 = mfma(kk[0], st[i], dq0);
+        dq1 = mfma(kk[1], st[i], dq1);
+      }
     }
     if (more) {
-      store_tile<kKs>(Kbuf[(kt + 1) & 1], tk, 1.0f);
-      store_tile<kKs>(Vbuf[(kt + 1) & 1], tv, 1.0f);
+      store_tile_interleaved(Kbuf[(kt + 1) & 1], tk, 1.0f);
+      store_tile_interleaved(Vbuf[(kt + 1) & 1], tv, 1.0f);
     }
     __syncthreads();
   }
@@ -343,8 +422,11 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_kernel(const float* __r
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // One workgroup = 4 waves = 128 keys of one (batch, head); loop over query tiles of 32.  Key on the lane:
-//   S' = Q . K^T + bias - LSE (query rows in the accumulator),  P = exp(S'),  dP = dO . V^T - delta,  dS = P o dP,
-//   dV^T += dO^T . P,  dK^T += (scale Q)^T . dS   (both sum over the query = the accumulators' row index).
+//   S = bias + (scale Q) . K^T (query rows in the accumulator),  P = exp(S - LSE),  dP = dO . V^T,
+//   dS = P o (dP - delta),  dV^T += dO^T . P,  dK^T += (scale Q)^T . dS  (both sum over the query = the accumulators'
+//   row index).  The per-query constants -LSE log2 e and delta ride in LDS next to the tiles, four consecutive
+//   accumulator rows per 16-byte read; the bias of this lane's key for the tile's query rows is 16 dword loads from a
+//   uniform row base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator.
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
@@ -357,9 +439,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
                                                                  AttnDims d, long dk_sb, long dk_ss, long dk_sh,
                                                                  long dv_sb, long dv_ss, long dv_sh, long go_sb,
                                                                  long go_ss, long go_sh) {
-  __shared__ float Qbuf[2][kTile * kKs];
-  __shared__ float Gbuf[2][kTile * kKs];
-  __shared__ float Lbuf[2][kTile], Dbuf[2][kTile];
+  __shared__ __attribute__((aligned(16))) float Qbuf[2][kTile * kVi];
+  __shared__ __attribute__((aligned(16))) float Gbuf[2][kTile * kVi];
+  __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
@@ -370,7 +452,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
   const float* qb = q + b * d.q_sb + head * d.q_sh;
   const float* gb = go + b * go_sb + head * go_sh;
-  const float* bb = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + kl : nullptr;
+  const float* bslab = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh : nullptr;   // uniform
+  const unsigned bvoff = HAS_BIAS ? static_cast<unsigned>(kl + 4 * h * static_cast<int>(d.bias_sr)) : 0u;
   const long rows = (static_cast<long>(b) * d.H + head) * d.Sq;
   float kf[32], vf[32];
 #pragma unroll
@@ -385,19 +468,38 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   }
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int n_tiles = (d.Sq + kTile - 1) / kTile;
-  // per-query row constants of a tile: thread t < 32 carries (lse, delta) of query q0 + t
+  // per-query row constants of a tile: thread t < 32 carries (-lse log2 e, delta) of query q0 + t
   auto row_consts = [&](int q0, float& rl, float& rd) {
     const int qq = q0 + static_cast<int>(threadIdx.x);
     const bool ok = threadIdx.x < kTile && qq < d.Sq;
-    rl = ok ? lse[rows + qq] : INFINITY;                             // a query beyond Sq: P = exp(-inf) = 0
+    rl = ok ? -lse[rows + qq] * kLog2e : -INFINITY;                  // a query beyond Sq: P = exp2(-inf) = 0
     rd = ok ? delta[rows + qq] : 0.0f;
   };
+  // bias[query q0 + acc_row(i, h)][this key]: a full tile reads from uniform row bases; the last, partial query tile
+  // clamps the row per lane (its P is 0 whatever is read)
+  auto load_bias = [&](int q0) {
+    f32x16 t;
+    if (q0 + kTile <= d.Sq) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        t[i] = (bslab + static_cast<long>(q0 + (i & 3) + 8 * (i >> 2)) * d.bias_sr)[bvoff];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = q0 + acc_row(i, h);
+        t[i] = bslab[static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * d.bias_sr + kl];
+      }
+    }
+    return t;
+  };
+  f32x16 bcur = {0};
+  if (HAS_BIAS && active) bcur = load_bias(0);
   {
-    const TileRegs tq = load_tile(qb, d.q_ss, 0, d.Sq), tg = load_tile(gb, go_ss, 0, d.Sq);
+    const TileRegs tq = load_tile_clamped(qb, d.q_ss, 0, d.Sq), tg = load_tile_clamped(gb, go_ss, 0, d.Sq);
     float rl, rd;
     row_consts(0, rl, rd);
-    store_tile<kKs>(Qbuf[0], tq, d.scale);
-    store_tile<kKs>(Gbuf[0], tg, 1.0f);
+    store_tile_interleaved(Qbuf[0], tq, d.scale);
+    store_tile_interleaved(Gbuf[0], tg, 1.0f);
     if (threadIdx.x < kTile) {
       Lbuf[0][threadIdx.x] = rl;
       Dbuf[0][threadIdx.x] = rd;
@@ -406,61 +508,56 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   __syncthreads();
   for (int qt = 0; qt < n_tiles; ++qt) {
     const int q0 = qt * kTile;
-    const float* Qs = Qbuf[qt & 1];
-    const float* Gs = Gbuf[qt & 1];
-    const float* Ls = Lbuf[qt & 1];
-    const float* Ds = Dbuf[qt & 1];
+    const float* Qr = Qbuf[qt & 1] + r * kVi + h;          // row read: Q[query r][32 h + s] at Qr[2 s]
+    const float* Gr = Gbuf[qt & 1] + r * kVi + h;
+    const float* Qc = Qbuf[qt & 1] + 4 * h * kVi + 2 * r;  // column read: Q[query][r], Q[query][r + 32]
+    const float* Gc = Gbuf[qt & 1] + 4 * h * kVi + 2 * r;
+    const float* Ls = Lbuf[qt & 1] + 4 * h;
+    const float* Ds = Dbuf[qt & 1] + 4 * h;
     const bool more = qt + 1 < n_tiles;
     TileRegs tq, tg;
     float rl = 0.0f, rd = 0.0f;
     if (more) {
-      tq = load_tile(qb, d.q_ss, q0 + kTile, d.Sq);
-      tg = load_tile(gb, go_ss, q0 + kTile, d.Sq);
+      tq = load_tile_clamped(qb, d.q_ss, q0 + kTile, d.Sq);
+      tg = load_tile_clamped(gb, go_ss, q0 + kTile, d.Sq);
       row_consts(q0 + kTile, rl, rd);
     }
     if (active) {
-    f32x16 st, dp;
+      f32x16 bnext = {0};
+      if (HAS_BIAS && more) bnext = load_bias(q0 + kTile);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 st = bcur, dp = {0};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int qr = acc_row(i, h);
-      st[i] = -Ls[qr];
-      dp[i] = -Ds[qr];
-    }
-    float bv[16];
-    if (HAS_BIAS) {                              // this key's bias for the tile's 16 query rows of this lane half
+      for (int s = 0; s < 32; ++s) {
+        st = mfma(Qr[2 * s], kf[s], st);
+        dp = mfma(Gr[2 * s], vf[s], dp);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 nl = *reinterpret_cast<const f32x4*>(Ls + 8 * g);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(Ds + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, nl[e]));   // P
+          dp[i] = st[i] * (dp[i] - dl[e]);                                         // dS
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int qq = q0 + acc_row(i, h);
-        bv[i] = bb[static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * d.bias_sr];
+        const int off = ((i & 3) + 8 * (i >> 2)) * kVi;
+        const f32x2 gg = *reinterpret_cast<const f32x2*>(Gc + off);
+        const f32x2 qq = *reinterpret_cast<const f32x2*>(Qc + off);
+        dv0 = mfma(gg[0], st[i], dv0);
+        dv1 = mfma(gg[1], st[i], dv1);
+        dk0 = mfma(qq[0], dp[i], dk0);
+        dk1 = mfma(qq[1], dp[i], dk1);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      st = mfma(Qs[r * kKs + s + 32 * h], kf[s], st);
-      dp = mfma(Gs[r * kKs + s + 32 * h], vf[s], dp);
-    }
-    if (HAS_BIAS) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) st[i] += bv[i];   // a query beyond Sq already has st = -inf
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      st[i] = __expf(st[i]);                     // P
-      dp[i] = st[i] * dp[i];                     // dS
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int qr = acc_row(i, h);
-      dv0 = mfma(Gs[qr * kKs + r], st[i], dv0);
-      dv1 = mfma(Gs[qr * kKs + 32 + r], st[i], dv1);
-      dk0 = mfma(Qs[qr * kKs + r], dp[i], dk0);
-      dk1 = mfma(Qs[qr * kKs + 32 + r], dp[i], dk1);
-    }
+      bcur = bnext;
     }
     if (more) {
-      store_tile<kKs>(Qbuf[(qt + 1) & 1], tq, d.scale);
-      store_tile<kKs>(Gbuf[(qt + 1) & 1], tg, 1.0f);
+      store_tile_interleaved(Qbuf[(qt + 1) & 1], tq, d.scale);
+      store_tile_interleaved(Gbuf[(qt + 1) & 1], tg, 1.0f);
       if (threadIdx.x < kTile) {
         Lbuf[(qt + 1) & 1][threadIdx.x] = rl;
         Dbuf[(qt + 1) & 1][threadIdx.x] = rd;
@@ -536,6 +633,8 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
     d.bias_sh = bias_strides[1];
     d.bias_sr = bias_strides[2];
     if (((d.bias_sb | d.bias_sh | d.bias_sr) & 3) || !aligned16(bias)) return VQA_ERR_ALIGN;
+    // the dK / dV kernel addresses a (batch, head) slab of the bias with 32-bit lane offsets
+    if (d.bias_sr < 0 || (static_cast<long>(Sq) + 4) * d.bias_sr + Sk >= 2147483647L) return VQA_ERR_SHAPE;
   }
   const int rc = check_attn(q, k, v, d);
   if (rc != VQA_OK) return rc;

@@ -230,8 +230,9 @@ class FrozenVlmo(nn.Module):
         gathered for the kept positions only -- a masked key contributes exp(-inf) = 0 to every softmax, so dropping
         it changes no result.  The masks depend only on the text batch, so an attack builds them ONCE per text batch
         and reuses them for every PGD step.  Layout choices that keep the fused attention kernel off the HBM roof:
-          * rows are padded to a multiple of 16 floats in storage and sliced back: the attention kernels read a row
-            in aligned 16-byte groups, and neither they nor the library re-pad (= copy) the mask on every call;
+          * rows are padded to a multiple of 32 floats in storage and sliced back: the attention kernels read a row
+            in whole 32-key tiles of aligned 16-byte groups, and neither they nor the library re-pad (= copy) the
+            mask on every call;
           * when every question of the batch has the same padding pattern (batches are bucketed by schedule and
             length) the mask is ONE (1, heads, S, S) slab expanded over the batch with stride 0: 18 MB per layer that
             stays cache-resident instead of a (B, heads, S, S) tensor (1.17 GB at batch 64) streamed by every
@@ -240,7 +241,7 @@ class FrozenVlmo(nn.Module):
         b, n_text = text_masks.shape
         dev = text_masks.device
         s = n_text + self.cfg.n_image_tokens
-        s_pad = (s + 15) // 16 * 16
+        s_pad = (s + 31) // 32 * 32
         keep = torch.cat([text_masks.bool(), torch.ones(b, self.cfg.n_image_tokens, dtype=torch.bool, device=dev)], dim=1)
         shared = bool((keep == keep[:1]).all())          # one host sync per text batch
         rows = keep[:1] if shared else keep
