@@ -12,6 +12,8 @@ its own batch of 64), plus
   * ``roofline``: the fused sign+clamp+project kernel (``vqa_linf_step``), timed live with HIP events on the launch
     stream inside the timed region; achieved = 16 B/element x elements per launch / mean launch duration, against the
     8 TB/s HBM3E peak; ``roofline_b256`` repeats it at the batch the north-star target is stated for.
+  * ``roofline_attention``: the white box's hand-written fp32 MFMA attention (``vqa_attn_fwd`` / ``vqa_attn_bwd``) at the
+    attack's shape, back-to-back, against the dense fp32 matrix peak (``bound`` = "mfma").
   * ``cpu_baseline``: the CPU oracle (reference op chain, reference-style batch-1 adapters) on the host cores, on a
     bounded sample (1 image, a few of the 40 steps, extrapolated), rank 0 / N == 1 only.
 """
@@ -32,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a float4 copy reaches
 STEP_BYTES_PER_ELEM = 16    # read x, grad, x0 + write x' 
+FP32_MFMA_PEAK_TFS = 157.3  # dense fp32 matrix peak, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -201,6 +204,58 @@ def step_kernel_microbench(batch, image_size, reps=40):
                 algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps))
 
 
+def attention_microbench(batch, heads, seq, with_bias, reps=10):
+    """The white box's fp32 MFMA attention (csrc/attn.hip) at the attack's shape: `reps` back-to-back forward launches
+    and `reps` backward launch pairs (dq + dk/dv kernels), one event pair around each group.  Flops are the useful ones
+    (2 S^2 d per product and (batch, head): 2 products forward, 3 + 4 backward incl. the recomputed scores), against
+    the dense fp32 matrix peak of v_mfma_f32_32x32x2_f32."""
+    from vqattack_amd import attention
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    qkv = torch.randn(batch, seq, 3, heads, 64, device="cuda", generator=gen)
+    bias, bstr = None, None
+    if with_bias:                                  # one (1, H, S, S) slab shared over the batch, rows padded to 32
+        store = torch.zeros(1, heads, seq, (seq + 31) // 32 * 32, device="cuda")
+        store[..., :seq] = torch.randn(1, heads, seq, seq, device="cuda", generator=gen) * 0.02
+        bias = store[..., :seq].expand(batch, -1, -1, -1)
+        bstr = (bias.stride(0), bias.stride(1), bias.stride(2))
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o, lse = attention.attention_forward(q, k, v, bias)
+    go = torch.randn(o.shape, device="cuda", generator=gen)
+    dqkv = torch.empty_like(qkv)
+
+    def fwd():
+        attention.attention_forward(q, k, v, bias)
+
+    def bwd():
+        attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], 0.125)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    product = 2.0 * batch * heads * seq * seq * 64
+    ms_f, ms_b = timed(fwd), timed(bwd)
+    tf_f, tf_b = 2 * product / ms_f / 1e9, 7 * product / ms_b / 1e9
+    tf = 9 * product / (ms_f + ms_b) / 1e9
+    return dict(kernel="vqa_attn_fwd + vqa_attn_bwd (attn_fwd_kernel, attn_bwd_dq_kernel, attn_bwd_dkv_kernel)",
+                bound="mfma", achieved=round(tf, 1), peak=FP32_MFMA_PEAK_TFS, unit="TFLOP/s",
+                frac=round(tf / FP32_MFMA_PEAK_TFS, 4), traffic=None,
+                shape=dict(batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias)),
+                forward=dict(ms=round(ms_f, 3), achieved=round(tf_f, 1), frac=round(tf_f / FP32_MFMA_PEAK_TFS, 4)),
+                backward=dict(ms=round(ms_b, 3), achieved=round(tf_b, 1), frac=round(tf_b / FP32_MFMA_PEAK_TFS, 4)),
+                useful_flops_per_call=9 * product,
+                timing="{} back-to-back launches per direction between two hip events (host launch gaps included); "
+                       "per-kernel durations inside the attack: profiles/r02/bench_b64_pgd40_summary.txt".format(reps))
+
+
 def baseline_config(args):
     """Which entry of BASELINE.json's ``configs`` the run is (the default run is configs[1])."""
     full = args.pgd_steps == 40 and args.image_size == 384
@@ -361,6 +416,12 @@ def main():
                 line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
             except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
                 line["roofline_b256"] = {"error": str(exc)[:200]}
+        if cfg.dim // cfg.heads == 64:                # the white box's attention runs on csrc/attn.hip
+            seq = (n_body + 2 if flavor == "vlmo" else 0) + cfg.n_image_tokens
+            try:
+                line["roofline_attention"] = attention_microbench(args.batch, cfg.heads, seq, flavor == "vlmo")
+            except RuntimeError as exc:
+                line["roofline_attention"] = {"error": str(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline and flavor == "vlmo":
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
