@@ -128,6 +128,30 @@ __device__ __forceinline__ void add_bias_mask(f32x16& st, const f32x4 (&bv)[4], 
   }
 }
 
+// Which (batch, head, block of 128 rows) a workgroup of the 1-D grid works on.  The blocks of one (batch, head) read the
+// same K / V (or Q / dO) tiles, and every batch of a head reads the same bias slab: workgroups are dealt round-robin
+// over the 8 XCDs, each with its own L2 (blockIdx % 8 labels the workgroups that share one), so the blocks of a pair
+// are given ids with equal id % 8 and pairs are ordered head-major -- an XCD then fetches a pair's tiles once instead
+// of once per block, and works on one or two bias slabs at a time.  Speed only; any placement is correct.
+struct BlockCoord {
+  int b, head, blk;
+};
+__device__ __forceinline__ BlockCoord block_coord(int n_blk, int B, int H) {
+  const int n = blockIdx.x, pairs = B * H;
+  const int grouped = (pairs & ~7) * n_blk;                 // the pairs that fill whole groups of 8
+  int p, blk;
+  if (n < grouped) {
+    const int j = n >> 3;
+    p = (n & 7) + 8 * (j / n_blk);
+    blk = j % n_blk;
+  } else {
+    const int m = n - grouped;
+    p = (pairs & ~7) + m / n_blk;
+    blk = m % n_blk;
+  }
+  return BlockCoord{p % B, p / B, blk};
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // On a CDNA4 SIMD vector instructions do not overlap the matrix pipe (tools/mfma_probe.hip: the tile loop's MFMAs alone
 // run at 65 cycles each, and every VALU instruction between them adds its own issue time, whatever the occupancy), so
@@ -206,8 +230,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * kTile;
+  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int b = bc.b, head = bc.head;
+  const int q0 = bc.blk * 128 + wave * kTile;
   const bool active = q0 < d.Sq;                           // a wave past the last query only helps staging the tiles
   const int qi = q0 + r;                                   // this lane's query
   const int ql = qi < d.Sq ? qi : d.Sq - 1;                // clamped for loads
@@ -331,9 +356,10 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
   __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int qi = blockIdx.x * 128 + wave * kTile + r;
-  const bool active = blockIdx.x * 128 + wave * kTile < d.Sq;
+  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int b = bc.b, head = bc.head;
+  const int qi = bc.blk * 128 + wave * kTile + r;
+  const bool active = bc.blk * 128 + wave * kTile < d.Sq;
   const int ql = qi < d.Sq ? qi : d.Sq - 1;
   const float* qp = q + b * d.q_sb + head * d.q_sh + static_cast<long>(ql) * d.q_ss + 32 * h;
   const float* gp = go + b * go_sb + head * go_sh + static_cast<long>(ql) * go_ss + 32 * h;
@@ -444,9 +470,10 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int ki = blockIdx.x * 128 + wave * kTile + r;                 // this lane's key
-  const bool active = blockIdx.x * 128 + wave * kTile < d.Sk;
+  const BlockCoord bc = block_coord((d.Sk + 127) / 128, d.B, d.H);
+  const int b = bc.b, head = bc.head;
+  const int ki = bc.blk * 128 + wave * kTile + r;                     // this lane's key
+  const bool active = bc.blk * 128 + wave * kTile < d.Sk;
   const int kl = ki < d.Sk ? ki : d.Sk - 1;
   const float* kp = k + b * d.k_sb + head * d.k_sh + static_cast<long>(kl) * d.k_ss + 32 * h;
   const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
@@ -588,6 +615,8 @@ extern "C" {
 static int check_attn(const float* q, const float* k, const float* v, const AttnDims& d) {
   if (!q || !k || !v) return VQA_ERR_NULL;
   if (d.B < 0 || d.H <= 0 || d.Sq <= 0 || d.Sk <= 0 || d.H > 65535 || d.B > 65535) return VQA_ERR_SHAPE;
+  const long blocks = ((d.Sq > d.Sk ? d.Sq : d.Sk) + 127L) / 128;
+  if (blocks * d.H * d.B > 2147483647L) return VQA_ERR_SHAPE;      // 1-D grid of (block, head, batch)
   if ((d.q_sb | d.q_ss | d.q_sh | d.k_sb | d.k_ss | d.k_sh | d.v_sb | d.v_ss | d.v_sh | d.o_sb | d.o_ss | d.o_sh) & 3)
     return VQA_ERR_SHAPE;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v)) return VQA_ERR_ALIGN;
@@ -611,7 +640,7 @@ int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bi
   if (rc != VQA_OK) return rc;
   if (!aligned16(o)) return VQA_ERR_ALIGN;
   if (B == 0) return VQA_OK;
-  dim3 grid((Sq + 127) / 128, H, B);
+  const dim3 grid(static_cast<unsigned>(((Sq + 127) / 128) * H * B));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (bias) attn_fwd_kernel<true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
   else attn_fwd_kernel<false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
@@ -645,7 +674,7 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
   if (B == 0) return VQA_OK;
   const long* g = grad_strides;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 gq((Sq + 127) / 128, H, B), gk((Sk + 127) / 128, H, B);
+  const dim3 gq(static_cast<unsigned>(((Sq + 127) / 128) * H * B)), gk(static_cast<unsigned>(((Sk + 127) / 128) * H * B));
   if (bias) {
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
                                                      g[2]);
