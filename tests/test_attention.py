@@ -55,8 +55,11 @@ def test_attention_forward_matches_sdpa(b, h, sq, sk, packed, bias_kind):
 
 @pytest.mark.parametrize("b,h,sq,sk", [(2, 3, 77, 77), (1, 2, 587, 587), (2, 1, 33, 160), (3, 4, 128, 128), (1, 1, 1, 5)])
 @pytest.mark.parametrize("bias_kind", ["none", "shared", "per_batch_padding"])
-def test_attention_backward_matches_sdpa(b, h, sq, sk, bias_kind):
+@pytest.mark.parametrize("workspace", [True, False], ids=["ds_workspace", "recompute"])
+def test_attention_backward_matches_sdpa(b, h, sq, sk, bias_kind, workspace, monkeypatch):
     from vqattack_amd import attention
+    if not workspace:                           # force the 7-product form that keeps no dS workspace
+        monkeypatch.setattr(attention, "DS_WORKSPACE_LIMIT", 0)
     q, k, v = (t.clone().requires_grad_(True) for t in _inputs(b, h, sq, sk, 2))
     bias = None
     if bias_kind == "shared":

@@ -89,20 +89,30 @@ def attention_forward(q, k, v, bias=None, scale=None):
     return _forward(*_prepare(q, k, v, bias, scale))
 
 
-def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale):
+# The backward keeps dS in a workspace (5 matrix products) when that workspace is at most this many bytes, and
+# recomputes the scores in both of its kernels (7 products, no workspace) above it.
+DS_WORKSPACE_LIMIT = 8 << 30
+
+
+def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale, workspace=True):
     b, sq, h, _ = q.shape
     sk = k.shape[1]
     if go.stride(-1) != 1 or any(s % 4 for s in go.stride()[:-1]) or go.data_ptr() % 16:
         go = go.contiguous()
     delta = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
+    ws = None
+    if workspace:
+        n = int(lib().vqa_attn_bwd_ws_floats(b, h, sq, sk))
+        if 0 < 4 * n <= DS_WORKSPACE_LIMIT:
+            ws = torch.empty(n, dtype=torch.float32, device=q.device)
     strides = _longs([q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                       v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
     gstr = _longs([go.stride(0), go.stride(1), go.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
                    dk.stride(0), dk.stride(1), dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2)])
     with torch.cuda.device(q.device):
         check(lib().vqa_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(go), ptr(lse), ptr(delta), ptr(dq),
-                                 ptr(dk), ptr(dv), b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr, scale,
-                                 stream_for(q)), "vqa_attn_bwd")
+                                 ptr(dk), ptr(dv), ptr(ws), b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr,
+                                 scale, stream_for(q)), "vqa_attn_bwd")
 
 
 class _Attention(torch.autograd.Function):

@@ -446,6 +446,112 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward via dS
+// With a workspace for dS^T (B, H, ceil128(Sk), ceil32(Sq)) the backward needs 5 products instead of 7: the dK / dV
+// kernel stores the dS tile it computes anyway (transposed: its lanes are keys, so a lane writes 16-byte runs of
+// queries into its own row), and dQ^T += K^T . dS^T becomes a kernel of one product per tile whose B operand is read
+// from that workspace with fully coalesced dword loads (lane = query).  delta = rowsum(dO o O), which the dQ kernel of
+// the recompute path produces on the way, comes from a small streaming pre-pass here.
+__host__ __device__ __forceinline__ long ds_rows(int Sk) { return (Sk + 127L) / 128 * 128; }
+__host__ __device__ __forceinline__ long ds_pitch(int Sq) { return (Sq + 31L) / 32 * 32; }
+
+// delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]: 16 lanes per row, one 16-byte load of each operand per lane
+__global__ __launch_bounds__(kBlock) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ go,
+                                                            float* __restrict__ delta, AttnDims d, long go_sb,
+                                                            long go_ss, long go_sh) {
+  const long row = static_cast<long>(blockIdx.x) * (kBlock / 16) + threadIdx.x / 16;      // (b, h, q) flattened
+  const long n_rows = static_cast<long>(d.B) * d.H * d.Sq;
+  const bool ok = row < n_rows;
+  const long rr = ok ? row : n_rows - 1;
+  const int qq = static_cast<int>(rr % d.Sq);
+  const int head = static_cast<int>((rr / d.Sq) % d.H);
+  const int b = static_cast<int>(rr / (static_cast<long>(d.Sq) * d.H));
+  const int c4 = (threadIdx.x & 15) * 4;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(o + b * d.o_sb + head * d.o_sh + static_cast<long>(qq) * d.o_ss + c4);
+  const f32x4 y = *reinterpret_cast<const f32x4*>(go + b * go_sb + head * go_sh + static_cast<long>(qq) * go_ss + c4);
+  float t = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+  t += __shfl_xor(t, 1, kWave);
+  t += __shfl_xor(t, 2, kWave);
+  t += __shfl_xor(t, 4, kWave);
+  t += __shfl_xor(t, 8, kWave);
+  if (ok && (threadIdx.x & 15) == 0) delta[row] = t;
+}
+
+// dQ^T += K^T . dS^T over the key tiles; one workgroup = 4 waves = 128 queries of one (batch, head).  No scores, no
+// exponentials: per tile 16 coalesced dword loads of dS^T (prefetched a tile ahead), 16 LDS reads, 32 MFMAs.
+__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const float* __restrict__ k,
+                                                                        const float* __restrict__ ds,
+                                                                        float* __restrict__ dq, AttnDims d, long dq_sb,
+                                                                        long dq_ss, long dq_sh) {
+  __shared__ __attribute__((aligned(16))) float Kbuf[2][kTile * kVi];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int r = lane & 31, h = lane >> 5;
+  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int b = bc.b, head = bc.head;
+  const int q0 = bc.blk * 128 + wave * kTile;
+  const int qi = q0 + r;
+  const bool active = q0 < d.Sq;
+  const float* kb = k + b * d.k_sb + head * d.k_sh;
+  const long pitch = ds_pitch(d.Sq);
+  const float* slab = ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * pitch;     // uniform
+  // an active wave's queries are < ceil32(Sq) = the pitch; a wave past the last query reads column 0 and discards it
+  const unsigned voff = static_cast<unsigned>(4 * h * pitch + (active ? qi : 0));
+  auto load_ds = [&](int k0) {
+    f32x16 t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)                  // read exactly once
+      t[i] = __builtin_nontemporal_load(slab + static_cast<long>(k0 + (i & 3) + 8 * (i >> 2)) * pitch + voff);
+    return t;
+  };
+  f32x16 dq0 = {0}, dq1 = {0};
+  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  // One tile: prefetch the next tile's K rows and dS^T values, run this tile's 32 MFMAs, publish the K tile.  Two
+  // register sets for dS^T alternate (the loop is unrolled by two) instead of "cur = next" copies: a copy would make the
+  // wave wait for the prefetch at the end of the tile it was issued in, and these loads come from HBM.  The prefetch
+  // is unconditional (the last tile prefetches itself again): straight-line code lets the compiler count exactly how
+  // many younger loads may stay in flight at each wait.
+  auto tile = [&](int kt, const f32x16& cur, f32x16& nxt) {
+    const int kn = kt + 1 < n_tiles ? kt + 1 : kt;
+    const float* Kc = Kbuf[kt & 1] + 4 * h * kVi + 2 * r;
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, kn * kTile, d.Sk);
+    nxt = load_ds(kn * kTile);                  // also in a wave without queries (clamped column): no branch around loads
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x2 kk = *reinterpret_cast<const f32x2*>(Kc + ((i & 3) + 8 * (i >> 2)) * kVi);
+        dq0 = mfma(kk[0], cur[i], dq0);
+        dq1 = mfma(kk[1], cur[i], dq1);
+      }
+    }
+    store_tile_interleaved(Kbuf[(kt + 1) & 1], tk, 1.0f);      // last read one tile ago, a barrier in between
+    __syncthreads();
+  };
+  f32x16 ds_a = load_ds(0), ds_b = {0};
+  {
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk);
+    store_tile_interleaved(Kbuf[0], tk, 1.0f);
+  }
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < n_tiles; kt += 2) {
+    tile(kt, ds_a, ds_b);
+    tile(kt + 1, ds_b, ds_a);
+  }
+  if (kt < n_tiles) tile(kt, ds_a, ds_b);
+  if (qi < d.Sq) {
+    float* dp_ = dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dim = 8 * g + 4 * h;
+      f32x4 a = {dq0[4 * g] * d.scale, dq0[4 * g + 1] * d.scale, dq0[4 * g + 2] * d.scale, dq0[4 * g + 3] * d.scale};
+      f32x4 c = {dq1[4 * g] * d.scale, dq1[4 * g + 1] * d.scale, dq1[4 * g + 2] * d.scale, dq1[4 * g + 3] * d.scale};
+      *reinterpret_cast<f32x4*>(dp_ + dim) = a;
+      *reinterpret_cast<f32x4*>(dp_ + 32 + dim) = c;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // One workgroup = 4 waves = 128 keys of one (batch, head); loop over query tiles of 32.  Key on the lane:
 //   S = bias + (scale Q) . K^T (query rows in the accumulator),  P = exp(S - LSE),  dP = dO . V^T,
@@ -453,7 +559,7 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
 //   row index).  The per-query constants -LSE log2 e and delta ride in LDS next to the tiles, four consecutive
 //   accumulator rows per 16-byte read; the bias of this lane's key for the tile's query rows is 16 dword loads from a
 //   uniform row base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator.
-template <bool HAS_BIAS>
+template <bool HAS_BIAS, bool STORE_DS>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
                                                                  const float* __restrict__ v,
@@ -464,7 +570,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
                                                                  float* __restrict__ dk, float* __restrict__ dv,
                                                                  AttnDims d, long dk_sb, long dk_ss, long dk_sh,
                                                                  long dv_sb, long dv_ss, long dv_sh, long go_sb,
-                                                                 long go_ss, long go_sh) {
+                                                                 long go_ss, long go_sh, float* __restrict__ ds) {
   __shared__ __attribute__((aligned(16))) float Qbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Gbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
@@ -474,6 +580,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const int b = bc.b, head = bc.head;
   const int ki = bc.blk * 128 + wave * kTile + r;                     // this lane's key
   const bool active = bc.blk * 128 + wave * kTile < d.Sk;
+  const bool all_live = bc.blk * 128 + wave * kTile + kTile <= d.Sk;    // wave-uniform
   const int kl = ki < d.Sk ? ki : d.Sk - 1;
   const float* kp = k + b * d.k_sb + head * d.k_sh + static_cast<long>(kl) * d.k_ss + 32 * h;
   const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
@@ -482,6 +589,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const float* bslab = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh : nullptr;   // uniform
   const unsigned bvoff = HAS_BIAS ? static_cast<unsigned>(kl + 4 * h * static_cast<int>(d.bias_sr)) : 0u;
   const long rows = (static_cast<long>(b) * d.H + head) * d.Sq;
+  // dS^T[(batch, head)][key][query], pitches ceil128(Sk) x ceil32(Sq): this lane's row, at its half's query offset
+  float* dsp = STORE_DS ? ds + ((static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) + ki) * ds_pitch(d.Sq) + 4 * h
+                        : nullptr;
   float kf[32], vf[32];
 #pragma unroll
   for (int s4 = 0; s4 < 8; ++s4) {
@@ -570,6 +680,19 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
           dp[i] = st[i] * (dp[i] - dl[e]);                                         // dS
         }
       }
+      if (STORE_DS) {                              // four consecutive queries per 16-byte store
+        if (all_live) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dsp + q0 + 8 * g) = f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]};
+        } else {                                   // the wave that straddles Sk: zeros in the rows of keys beyond it
+          const bool live = ki < d.Sk;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dsp + q0 + 8 * g) =
+                live ? f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int off = ((i & 3) + 8 * (i >> 2)) * kVi;
@@ -647,10 +770,15 @@ int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bi
   return launch_status();
 }
 
+long vqa_attn_bwd_ws_floats(int B, int H, int Sq, int Sk) {
+  if (B < 0 || H <= 0 || Sq <= 0 || Sk <= 0) return 0;
+  return static_cast<long>(B) * H * ds_rows(Sk) * ds_pitch(Sq);
+}
+
 /* grad_strides: 12 longs = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} */
 int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
-                 const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Sq, int Sk,
-                 const long* strides, const long* bias_strides, const long* grad_strides, float scale,
+                 const float* lse, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B, int H, int Sq,
+                 int Sk, const long* strides, const long* bias_strides, const long* grad_strides, float scale,
                  vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !grad_strides || !o || !go || !lse || !delta || !dq || !dk || !dv || (bias && !bias_strides))
@@ -670,21 +798,36 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
   long any = 0;
   for (int i = 0; i < 12; ++i) any |= grad_strides[i];
   if (any & 3) return VQA_ERR_SHAPE;
-  if (!aligned16(o) || !aligned16(go) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv)) return VQA_ERR_ALIGN;
+  if (!aligned16(o) || !aligned16(go) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(ds_ws))
+    return VQA_ERR_ALIGN;
+  // the dS path addresses a (batch, head) slab of the workspace with 32-bit lane offsets
+  if (ds_ws && ds_rows(Sk) * ds_pitch(Sq) >= 2147483647L) return VQA_ERR_SHAPE;
   if (B == 0) return VQA_OK;
   const long* g = grad_strides;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 gq(static_cast<unsigned>(((Sq + 127) / 128) * H * B)), gk(static_cast<unsigned>(((Sk + 127) / 128) * H * B));
-  if (bias) {
+  if (ds_ws) {                                   // 5 products: delta pre-pass, dK / dV (+ dS^T store), dQ from dS^T
+    const long n_rows = static_cast<long>(B) * H * Sq;
+    const long blocks = (n_rows + kBlock / 16 - 1) / (kBlock / 16);
+    if (blocks > 2147483647L) return VQA_ERR_SHAPE;
+    attn_delta_kernel<<<dim3(static_cast<unsigned>(blocks)), kBlock, 0, st>>>(o, go, delta, d, g[0], g[1], g[2]);
+    if (bias)
+      attn_bwd_dkv_kernel<true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
+                                                             g[9], g[10], g[11], g[0], g[1], g[2], ds_ws);
+    else
+      attn_bwd_dkv_kernel<false, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
+                                                              g[9], g[10], g[11], g[0], g[1], g[2], ds_ws);
+    attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
+  } else if (bias) {                             // no workspace: 7 products, both kernels recompute the scores
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
                                                      g[2]);
-    attn_bwd_dkv_kernel<true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8], g[9],
-                                                      g[10], g[11], g[0], g[1], g[2]);
+    attn_bwd_dkv_kernel<true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
+                                                            g[9], g[10], g[11], g[0], g[1], g[2], nullptr);
   } else {
     attn_bwd_dq_kernel<false><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0],
                                                       g[1], g[2]);
-    attn_bwd_dkv_kernel<false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8], g[9],
-                                                       g[10], g[11], g[0], g[1], g[2]);
+    attn_bwd_dkv_kernel<false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
+                                                             g[9], g[10], g[11], g[0], g[1], g[2], nullptr);
   }
   return launch_status();
 }
