@@ -206,8 +206,8 @@ def step_kernel_microbench(batch, image_size, reps=40):
 
 def attention_microbench(batch, heads, seq, with_bias, reps=10):
     """The white box's fp32 MFMA attention (csrc/attn.hip) at the attack's shape: `reps` back-to-back forward launches
-    and `reps` backward calls (delta pre-pass, dK / dV kernel that also stores dS^T, dQ-from-dS^T kernel), one event pair
-    around each group.  Flops are the algorithm's (2 S^2 d per matrix product and (batch, head): 2 products forward, 5
+    (saving the scores, as a differentiated forward does) and `reps` backward calls (delta pre-pass, dK / dV kernel that
+    starts from the saved scores and stores dS^T, dQ-from-dS^T kernel), one event pair around each group.  Flops are the algorithm's (2 S^2 d per matrix product and (batch, head): 2 products forward, 5
     backward -- the usual flash-attention accounting), against the dense fp32 matrix peak of v_mfma_f32_32x32x2_f32."""
     from vqattack_amd import attention
     gen = torch.Generator(device="cuda").manual_seed(2)
@@ -219,15 +219,17 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
         bias = store[..., :seq].expand(batch, -1, -1, -1)
         bstr = (bias.stride(0), bias.stride(1), bias.stride(2))
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    o, lse = attention.attention_forward(q, k, v, bias)
+    # what the attack's autograd path runs: a forward that saves its scores, a backward that starts from them
+    o, lse, scores = attention._forward(q, k, v, bias, bstr, 0.125, save_scores=True)
     go = torch.randn(o.shape, device="cuda", generator=gen)
     dqkv = torch.empty_like(qkv)
 
     def fwd():
-        attention.attention_forward(q, k, v, bias)
+        attention._forward(q, k, v, bias, bstr, 0.125, save_scores=True)
 
     def bwd():
-        attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], 0.125)
+        attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], 0.125,
+                            scores=scores)
 
     def timed(fn):
         for _ in range(2):
@@ -243,8 +245,8 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
 
     product = 2.0 * batch * heads * seq * seq * 64
     ms_f, ms_b = timed(fwd), timed(bwd)
-    tf_f, tf_b = 2 * product / ms_f / 1e9, 5 * product / ms_b / 1e9
-    tf = 7 * product / (ms_f + ms_b) / 1e9
+    tf_f, tf_b = 2 * product / ms_f / 1e9, 4 * product / ms_b / 1e9
+    tf = 6 * product / (ms_f + ms_b) / 1e9
     return dict(kernel="vqa_attn_fwd + vqa_attn_bwd (attn_fwd_kernel; attn_delta_kernel, attn_bwd_dkv_kernel, "
                        "attn_bwd_dq_from_ds_kernel)",
                 bound="mfma", achieved=round(tf, 1), peak=FP32_MFMA_PEAK_TFS, unit="TFLOP/s",
@@ -252,8 +254,10 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
                 shape=dict(batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias)),
                 forward=dict(ms=round(ms_f, 3), achieved=round(tf_f, 1), frac=round(tf_f / FP32_MFMA_PEAK_TFS, 4)),
                 backward=dict(ms=round(ms_b, 3), achieved=round(tf_b, 1), frac=round(tf_b / FP32_MFMA_PEAK_TFS, 4)),
-                flops_per_call=7 * product,
-                note="the backward also moves its dS^T workspace through HBM once each way ({:.2f} GB)".format(
+                flops_per_call=6 * product,
+                flash_accounting=dict(products=7, achieved=round(7 * product / (ms_f + ms_b) / 1e9, 1),
+                                      frac=round(7 * product / (ms_f + ms_b) / 1e9 / FP32_MFMA_PEAK_TFS, 4)),
+                note="saved scores and the dS^T workspace each cross HBM once each way ({:.2f} GB per direction)".format(
                     2 * 4 * batch * heads * ((seq + 127) // 128 * 128) * ((seq + 31) // 32 * 32) / 1e9),
                 timing="{} back-to-back launches per direction between two hip events (host launch gaps included); "
                        "per-kernel durations inside the attack: profiles/r02/bench_b64_pgd40_summary.txt".format(reps))

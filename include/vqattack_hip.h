@@ -255,23 +255,30 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
  * bias (nullable): additive fp32 (relative-position bias and/or -inf key padding), bias_strides[3] = {batch, head, query
  * row} in elements (batch / head stride may be 0, all multiples of 4), key stride 1.  The kernels read bias rows in
  * whole tiles of 32 keys: from every row start, ceil32(Sk) floats must be readable (pad the rows; what lies beyond Sk
- * is masked, never used).  lse (B, H, Sq) receives log-sum-exp of the scores. */
-int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, int B, int H,
-                 int Sq, int Sk, const long* strides, const long* bias_strides, float scale, vqa_stream_t stream);
+ * is masked, never used).  lse (B, H, Sq) receives log-sum-exp of the scores.
+ * scores (nullable; vqa_attn_scores_floats(B, H, Sq, Sk) floats, 16-byte aligned): when given, the forward also stores
+ * the pre-softmax scores scale * q k^T + bias -- a forward that will be differentiated hands them to vqa_attn_bwd, whose
+ * key-block kernel then skips the q k^T product and the bias. */
+int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
+                 int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
+                 vqa_stream_t stream);
+long vqa_attn_scores_floats(int B, int H, int Sq, int Sk);
 
 /* Gradients of the above w.r.t. q, k, v given go = d loss / d o (the bias is frozen: no gradient).  Deterministic (no
  * float atomics: bitwise reproducible), two forms:
  *   ds_ws != NULL (vqa_attn_bwd_ws_floats(B, H, Sq, Sk) floats, 16-byte aligned, contents irrelevant): 5 products.  A
  *     streaming pre-pass writes delta (B, H, Sq) = rowsum(go . o); the kernel that owns key blocks computes dk, dv and
- *     stores the dS tiles it forms on the way, transposed, into ds_ws; a third kernel forms dq from them.
+ *     stores the dS tiles it forms on the way, transposed, into ds_ws; a third kernel forms dq from them.  With
+ *     scores != NULL (what vqa_attn_fwd stored for the same operands) the key-block kernel reads the scores instead of
+ *     recomputing them: 4 products.
  *   ds_ws == NULL: 7 products, no workspace: one kernel owns query blocks (dq; it also writes delta), one owns key
  *     blocks (dk, dv); both recompute the probabilities from lse.
  * grad_strides[12] = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} (elements;
  * dq / dk / dv may be the three slices of one packed (B, S, 3, H, 64) gradient buffer). */
 int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
-                 const float* lse, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B, int H, int Sq,
-                 int Sk, const long* strides, const long* bias_strides, const long* grad_strides, float scale,
-                 vqa_stream_t stream);
+                 const float* lse, const float* scores, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B,
+                 int H, int Sq, int Sk, const long* strides, const long* bias_strides, const long* grad_strides,
+                 float scale, vqa_stream_t stream);
 long vqa_attn_bwd_ws_floats(int B, int H, int Sq, int Sk);
 
 /* ---------------------------------------------------------------- input pipeline

@@ -55,10 +55,12 @@ def test_attention_forward_matches_sdpa(b, h, sq, sk, packed, bias_kind):
 
 @pytest.mark.parametrize("b,h,sq,sk", [(2, 3, 77, 77), (1, 2, 587, 587), (2, 1, 33, 160), (3, 4, 128, 128), (1, 1, 1, 5)])
 @pytest.mark.parametrize("bias_kind", ["none", "shared", "per_batch_padding"])
-@pytest.mark.parametrize("workspace", [True, False], ids=["ds_workspace", "recompute"])
-def test_attention_backward_matches_sdpa(b, h, sq, sk, bias_kind, workspace, monkeypatch):
+@pytest.mark.parametrize("form", ["saved_scores", "ds_workspace", "recompute"])
+def test_attention_backward_matches_sdpa(b, h, sq, sk, bias_kind, form, monkeypatch):
     from vqattack_amd import attention
-    if not workspace:                           # force the 7-product form that keeps no dS workspace
+    if form != "saved_scores":                  # the forward keeps no scores: 5 products with the dS workspace ...
+        monkeypatch.setattr(attention, "SCORES_LIMIT", 0)
+    if form == "recompute":                     # ... or the 7-product form that needs no workspace at all
         monkeypatch.setattr(attention, "DS_WORKSPACE_LIMIT", 0)
     q, k, v = (t.clone().requires_grad_(True) for t in _inputs(b, h, sq, sk, 2))
     bias = None

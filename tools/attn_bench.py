@@ -59,13 +59,19 @@ def main():
         ms = timeit(hip_packed)
         print(json.dumps(dict(what="hip packed fwd+bwd", ms=round(ms, 3),
                               TFLOPs=round(3.5 * flops_fwd / ms / 1e9, 1))), flush=True)
-        o, lse = attention.attention_forward(q, k, v, bias)
-        dqkv = torch.empty_like(qkv)
         bstr = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else None
-        ms = timeit(lambda: attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
-                                                dqkv[:, :, 2], D ** -0.5))
-        print(json.dumps(dict(what="hip bwd kernels", ms=round(ms, 3), TFLOPs=round(2.5 * flops_fwd / ms / 1e9, 1))),
-              flush=True)
+        ms = timeit(lambda: attention._forward(q, k, v, bias, bstr, D ** -0.5, save_scores=True))
+        print(json.dumps(dict(what="hip fwd saving its scores", ms=round(ms, 3),
+                              TFLOPs=round(flops_fwd / ms / 1e9, 1))), flush=True)
+        o, lse, scores = attention._forward(q, k, v, bias, bstr, D ** -0.5, save_scores=True)
+        dqkv = torch.empty_like(qkv)
+        for what, kw in (("hip bwd kernels, from saved scores", dict(scores=scores)),
+                         ("hip bwd kernels, dS workspace only", dict()),
+                         ("hip bwd kernels, recompute form", dict(workspace=False))):
+            ms = timeit(lambda: attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
+                                                    dqkv[:, :, 2], D ** -0.5, **kw))
+            print(json.dumps(dict(what=what, ms=round(ms, 3), TFLOPs=round(2.5 * flops_fwd / ms / 1e9, 1))),
+                  flush=True)
 
         def sdpa_fb():
             o = F.scaled_dot_product_attention(qkv_l[:, :, 0].transpose(1, 2), qkv_l[:, :, 1].transpose(1, 2),

@@ -61,17 +61,23 @@ def _longs(vals):
     return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
 
 
-def _forward(q, k, v, bias, bstr, scale):
+def _forward(q, k, v, bias, bstr, scale, save_scores=False):
+    """Returns (o, lse, scores); ``scores`` is None unless ``save_scores`` and the buffer fits SCORES_LIMIT."""
     b, sq, h, _ = q.shape
     sk = k.shape[1]
     o = torch.empty((b, sq, h, HEAD_DIM), dtype=torch.float32, device=q.device)
     lse = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
+    scores = None
+    if save_scores:
+        n = int(lib().vqa_attn_scores_floats(b, h, sq, sk))
+        if 0 < 4 * n <= SCORES_LIMIT and 0 < 4 * int(lib().vqa_attn_bwd_ws_floats(b, h, sq, sk)) <= DS_WORKSPACE_LIMIT:
+            scores = torch.empty(n, dtype=torch.float32, device=q.device)
     strides = _longs([q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                       v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
     with torch.cuda.device(q.device):
-        check(lib().vqa_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(lse), b, h, sq, sk, strides,
+        check(lib().vqa_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(lse), ptr(scores), b, h, sq, sk, strides,
                                  _longs(bstr) if bstr else None, scale, stream_for(q)), "vqa_attn_fwd")
-    return o, lse
+    return o, lse, scores
 
 
 def _prepare(q, k, v, bias, scale):
@@ -86,15 +92,19 @@ def _prepare(q, k, v, bias, scale):
 
 def attention_forward(q, k, v, bias=None, scale=None):
     """Forward only; returns ``(o (B, Sq, H, 64), lse (B, H, Sq))``."""
-    return _forward(*_prepare(q, k, v, bias, scale))
+    return _forward(*_prepare(q, k, v, bias, scale))[:2]
 
 
-# The backward keeps dS in a workspace (5 matrix products) when that workspace is at most this many bytes, and
-# recomputes the scores in both of its kernels (7 products, no workspace) above it.
+# The backward keeps dS in a transient workspace (5 matrix products) when that workspace is at most this many bytes,
+# and recomputes the scores in both of its kernels (7 products, no workspace) above it.
 DS_WORKSPACE_LIMIT = 8 << 30
+# A forward that will be differentiated also saves its pre-softmax scores for the backward (4 products) when they are
+# at most this many bytes per call; they live from the forward to the backward of the same layer (12-24 layers deep:
+# 14 GB for VLMO-base at batch 64, 58 GB for ALBEF-base at batch 256, of the 288 GB of HBM).
+SCORES_LIMIT = 6 << 30
 
 
-def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale, workspace=True):
+def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale, workspace=True, scores=None):
     b, sq, h, _ = q.shape
     sk = k.shape[1]
     if go.stride(-1) != 1 or any(s % 4 for s in go.stride()[:-1]) or go.data_ptr() % 16:
@@ -110,9 +120,10 @@ def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale, workspace=True
     gstr = _longs([go.stride(0), go.stride(1), go.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
                    dk.stride(0), dk.stride(1), dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2)])
     with torch.cuda.device(q.device):
-        check(lib().vqa_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(go), ptr(lse), ptr(delta), ptr(dq),
-                                 ptr(dk), ptr(dv), ptr(ws), b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr,
-                                 scale, stream_for(q)), "vqa_attn_bwd")
+        check(lib().vqa_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(go), ptr(lse),
+                                 ptr(scores if ws is not None else None), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(ws),
+                                 b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr, scale, stream_for(q)),
+              "vqa_attn_bwd")
 
 
 class _Attention(torch.autograd.Function):
@@ -122,18 +133,18 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, q, k, v, bias, scale):
         q, k, v, bias_t, bstr, scale = _prepare(q.detach(), k.detach(), v.detach(),
                                                 None if bias is None else bias.detach(), scale)
-        o, lse = _forward(q, k, v, bias_t, bstr, scale)
-        ctx.save_for_backward(q, k, v, o, lse, bias_t)
+        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=any(ctx.needs_input_grad[:3]))
+        ctx.save_for_backward(q, k, v, o, lse, bias_t, scores)
         ctx.bstr, ctx.scale = bstr, scale
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, o, lse, bias = ctx.saved_tensors
+        q, k, v, o, lse, bias, scores = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
             torch.empty_like(k, memory_format=torch.contiguous_format), \
             torch.empty_like(v, memory_format=torch.contiguous_format)
-        _backward(q, k, v, bias, ctx.bstr, o, lse, go, dq, dk, dv, ctx.scale)
+        _backward(q, k, v, bias, ctx.bstr, o, lse, go, dq, dk, dv, ctx.scale, scores=scores)
         return dq, dk, dv, None, None
 
 
@@ -148,17 +159,17 @@ class _PackedSelfAttention(torch.autograd.Function):
             qkv = qkv.contiguous()
         q, k, v, bias_t, bstr, scale = _prepare(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2],
                                                 None if bias is None else bias.detach(), scale)
-        o, lse = _forward(q, k, v, bias_t, bstr, scale)
-        ctx.save_for_backward(qkv, o, lse, bias_t)
+        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=ctx.needs_input_grad[0])
+        ctx.save_for_backward(qkv, o, lse, bias_t, scores)
         ctx.bstr, ctx.scale = bstr, scale
         return o
 
     @staticmethod
     def backward(ctx, go):
-        qkv, o, lse, bias = ctx.saved_tensors
+        qkv, o, lse, bias, scores = ctx.saved_tensors
         dqkv = torch.empty_like(qkv)
         _backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias, ctx.bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
-                  dqkv[:, :, 2], ctx.scale)
+                  dqkv[:, :, 2], ctx.scale, scores=scores)
         return dqkv, None, None
 
 

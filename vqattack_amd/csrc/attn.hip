@@ -23,10 +23,8 @@ namespace vqa {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kHeadDim = 64;
 constexpr int kTile = 32;               // keys (or queries) per MFMA tile
 constexpr int kKs = 65;                 // LDS row stride for "row on the lane" reads  (bank = (row + col) % 64)
-constexpr int kVs = 72;                 // LDS row stride for "column on the lane" reads of rows r and r + 4
 
 struct AttnDims {
   int B, H, Sq, Sk;
@@ -44,45 +42,12 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// Cooperative load of a 32 x 64 tile (rows [row0, row0 + 32) of a (seq, 64) matrix with row stride `ss`) into LDS with
-// row stride STRIDE; rows >= n_rows are zero-filled.  256 threads, two 16-byte loads each.
-template <int STRIDE>
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ base, long ss, int row0, int n_rows,
-                                           float mul) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int idx = threadIdx.x * 2 + j;          // float4 index within the tile
-    const int row = idx >> 4, c4 = (idx & 15) * 4;
-    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (row0 + row < n_rows) v = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row0 + row) * ss + c4);
-    float* dst = lds + row * STRIDE + c4;
-    if (STRIDE % 4 == 0) {
-      *reinterpret_cast<f32x4*>(dst) = v * mul;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dst[e] = v[e] * mul;
-    }
-  }
-}
-
-// The same tile in two steps, for software pipelining: the global loads of tile t + 1 are issued into registers before
-// tile t is computed and are written to the OTHER LDS buffer after it, so their latency hides behind ~4000 MFMA cycles
-// and a tile costs one barrier.
+// A 32 x 64 tile (rows of a (seq, 64) matrix) moves in two steps, for software pipelining: the global loads of tile
+// t + 1 are issued into registers before tile t is computed and are written to the OTHER LDS buffer after it, so their
+// latency hides behind ~4000 MFMA cycles and a tile costs one barrier.  256 threads, two 16-byte loads each.
 struct TileRegs {
   f32x4 v[2];
 };
-
-__device__ __forceinline__ TileRegs load_tile(const float* __restrict__ base, long ss, int row0, int n_rows) {
-  TileRegs t;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int idx = threadIdx.x * 2 + j;
-    const int row = idx >> 4, c4 = (idx & 15) * 4;
-    t.v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (row0 + row < n_rows) t.v[j] = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row0 + row) * ss + c4);
-  }
-  return t;
-}
 
 template <int STRIDE>
 __device__ __forceinline__ void store_tile(float* lds, const TileRegs& t, float mul) {
@@ -96,34 +61,6 @@ __device__ __forceinline__ void store_tile(float* lds, const TileRegs& t, float 
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) dst[e] = t.v[j][e] * mul;
-    }
-  }
-}
-
-// Bias of one query row for the 32 keys of a tile in the S^T accumulator layout: lane half h holds keys
-// k0 + 8 g + 4 h + e (g, e < 4), i.e. four 16-byte loads.  Always issued (no branches, so they overlap the MFMA chain);
-// a group beyond the last key reads the row's last aligned group instead -- rows span at least ceil4(Sk) floats
-// (attention.py pads them) -- and add_bias_mask discards it.
-template <bool HAS_BIAS>
-__device__ __forceinline__ void load_bias_row(f32x4 (&bv)[4], const float* __restrict__ bp, int k0, int h, int Sk) {
-  if (!HAS_BIAS) return;
-  const int last = ((Sk + 3) & ~3) - 4;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int key = k0 + 8 * g + 4 * h;
-    bv[g] = *reinterpret_cast<const f32x4*>(bp + (key < last ? key : last));
-  }
-}
-
-template <bool HAS_BIAS>
-__device__ __forceinline__ void add_bias_mask(f32x16& st, const f32x4 (&bv)[4], int k0, int h, int Sk) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int key = k0 + 8 * g + 4 * h + e;
-      const float x = HAS_BIAS ? st[4 * g + e] + bv[g][e] : st[4 * g + e];
-      st[4 * g + e] = key < Sk ? x : -INFINITY;
     }
   }
 }
@@ -166,6 +103,14 @@ __device__ __forceinline__ BlockCoord block_coord(int n_blk, int B, int H) {
 //   * keys beyond Sk are masked in the last tile only; tile rows beyond the sequence are clamped, not zero-filled;
 //   * V sits in LDS with dimensions d and d + 32 interleaved, so one ds_read_b64 with an immediate offset feeds both
 //     P.V products of a key and no address arithmetic is left in the loop.
+// Row counts / pitches of the two optional workspaces: scores (B, H, ceil128(Sq), ceil32(Sk)) written by the forward
+// and dS^T (B, H, ceil128(Sk), ceil32(Sq)) written by the dK / dV kernel.  Rows go up to the workgroup's 128 so that
+// every lane of a live wave owns one; pitches are whole 32-wide tiles.
+__host__ __device__ __forceinline__ long sc_rows(int Sq) { return (Sq + 127L) / 128 * 128; }
+__host__ __device__ __forceinline__ long sc_pitch(int Sk) { return (Sk + 31L) / 32 * 32; }
+__host__ __device__ __forceinline__ long ds_rows(int Sk) { return (Sk + 127L) / 128 * 128; }
+__host__ __device__ __forceinline__ long ds_pitch(int Sq) { return (Sq + 31L) / 32 * 32; }
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kLazyMax = 8.0f;
@@ -221,11 +166,12 @@ __device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ row, 
   return b;
 }
 
-template <bool HAS_BIAS>
+template <bool HAS_BIAS, bool STORE_S>
 __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v,
                                                              const float* __restrict__ bias, float* __restrict__ o,
-                                                             float* __restrict__ lse, AttnDims d) {
+                                                             float* __restrict__ lse, float* __restrict__ scores,
+                                                             AttnDims d) {
   __shared__ float Kbuf[2][kTile * kKs];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -241,6 +187,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   const float* vb = v + b * d.v_sb + head * d.v_sh;
   const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr + 4 * h
                              : nullptr;
+  // scores[(batch, head)][query][key], pitches ceil128(Sq) x ceil32(Sk): this lane's row, at its half's key offset
+  float* scp = STORE_S ? scores + ((static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) + qi) * sc_pitch(d.Sk) + 4 * h
+                       : nullptr;
   float qf[32];                                            // Q[query][32 h + s] * scale: the B operand of S^T = K . Q^T
 #pragma unroll
   for (int s4 = 0; s4 < 8; ++s4) {
@@ -276,6 +225,11 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
       f32x16 st = bcur;                          // S^T = bias + K . (scale Q)^T, key on the accumulator row
 #pragma unroll
       for (int s = 0; s < 32; ++s) st = mfma(Ks[s], qf[s], st);
+      if (STORE_S) {                             // the backward's dK / dV kernel starts from these instead of Q . K^T
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(scp + k0 + 8 * g) = f32x4{st[4 * g], st[4 * g + 1], st[4 * g + 2], st[4 * g + 3]};
+      }
       if (k0 + kTile > d.Sk) {                   // last, partial tile: keys beyond Sk never win the softmax
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = k0 + acc_row(i, h) < d.Sk ? st[i] : -INFINITY;
@@ -452,9 +406,6 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
 // queries into its own row), and dQ^T += K^T . dS^T becomes a kernel of one product per tile whose B operand is read
 // from that workspace with fully coalesced dword loads (lane = query).  delta = rowsum(dO o O), which the dQ kernel of
 // the recompute path produces on the way, comes from a small streaming pre-pass here.
-__host__ __device__ __forceinline__ long ds_rows(int Sk) { return (Sk + 127L) / 128 * 128; }
-__host__ __device__ __forceinline__ long ds_pitch(int Sq) { return (Sq + 31L) / 32 * 32; }
-
 // delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]: 16 lanes per row, one 16-byte load of each operand per lane
 __global__ __launch_bounds__(kBlock) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ go,
                                                             float* __restrict__ delta, AttnDims d, long go_sb,
@@ -559,7 +510,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const fl
 //   row index).  The per-query constants -LSE log2 e and delta ride in LDS next to the tiles, four consecutive
 //   accumulator rows per 16-byte read; the bias of this lane's key for the tile's query rows is 16 dword loads from a
 //   uniform row base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator.
-template <bool HAS_BIAS, bool STORE_DS>
+template <bool HAS_BIAS, bool STORE_DS, bool FROM_SCORES>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
                                                                  const float* __restrict__ v,
@@ -570,7 +521,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
                                                                  float* __restrict__ dk, float* __restrict__ dv,
                                                                  AttnDims d, long dk_sb, long dk_ss, long dk_sh,
                                                                  long dv_sb, long dv_ss, long dv_sh, long go_sb,
-                                                                 long go_ss, long go_sh, float* __restrict__ ds) {
+                                                                 long go_ss, long go_sh, float* __restrict__ ds,
+                                                                 const float* __restrict__ scores) {
   __shared__ __attribute__((aligned(16))) float Qbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Gbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
@@ -586,8 +538,14 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
   const float* qb = q + b * d.q_sb + head * d.q_sh;
   const float* gb = go + b * go_sb + head * go_sh;
-  const float* bslab = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh : nullptr;   // uniform
-  const unsigned bvoff = HAS_BIAS ? static_cast<unsigned>(kl + 4 * h * static_cast<int>(d.bias_sr)) : 0u;
+  // The S chain's initial accumulator: the bias tile -- or, when the forward saved its scores (bias included), the
+  // scores themselves, and the chain is not run at all.  Either way a (query row, key) matrix of one (batch, head).
+  constexpr bool kInit = HAS_BIAS || FROM_SCORES;
+  const long init_sr = FROM_SCORES ? sc_pitch(d.Sk) : d.bias_sr;
+  const float* bslab = FROM_SCORES ? scores + (static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) * sc_pitch(d.Sk)
+                       : HAS_BIAS  ? bias + b * d.bias_sb + head * d.bias_sh
+                                   : nullptr;                                          // uniform
+  const unsigned bvoff = kInit ? static_cast<unsigned>(kl + 4 * h * static_cast<int>(init_sr)) : 0u;
   const long rows = (static_cast<long>(b) * d.H + head) * d.Sq;
   // dS^T[(batch, head)][key][query], pitches ceil128(Sk) x ceil32(Sq): this lane's row, at its half's query offset
   float* dsp = STORE_DS ? ds + ((static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) + ki) * ds_pitch(d.Sq) + 4 * h
@@ -619,18 +577,18 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     if (q0 + kTile <= d.Sq) {
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        t[i] = (bslab + static_cast<long>(q0 + (i & 3) + 8 * (i >> 2)) * d.bias_sr)[bvoff];
+        t[i] = (bslab + static_cast<long>(q0 + (i & 3) + 8 * (i >> 2)) * init_sr)[bvoff];
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qq = q0 + acc_row(i, h);
-        t[i] = bslab[static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * d.bias_sr + kl];
+        t[i] = bslab[static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * init_sr + kl];
       }
     }
     return t;
   };
   f32x16 bcur = {0};
-  if (HAS_BIAS && active) bcur = load_bias(0);
+  if (kInit && active) bcur = load_bias(0);
   {
     const TileRegs tq = load_tile_clamped(qb, d.q_ss, 0, d.Sq), tg = load_tile_clamped(gb, go_ss, 0, d.Sq);
     float rl, rd;
@@ -661,13 +619,18 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     }
     if (active) {
       f32x16 bnext = {0};
-      if (HAS_BIAS && more) bnext = load_bias(q0 + kTile);
+      if (kInit && more) bnext = load_bias(q0 + kTile);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 st = bcur, dp = {0};
+      if (FROM_SCORES) {
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        st = mfma(Qr[2 * s], kf[s], st);
-        dp = mfma(Gr[2 * s], vf[s], dp);
+        for (int s = 0; s < 32; ++s) dp = mfma(Gr[2 * s], vf[s], dp);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          st = mfma(Qr[2 * s], kf[s], st);
+          dp = mfma(Gr[2 * s], vf[s], dp);
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -747,8 +710,14 @@ static int check_attn(const float* q, const float* k, const float* v, const Attn
 }
 
 /* strides: 12 longs = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh}; bias_strides: 3 longs */
-int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, int B, int H,
-                 int Sq, int Sk, const long* strides, const long* bias_strides, float scale, vqa_stream_t stream) {
+long vqa_attn_scores_floats(int B, int H, int Sq, int Sk) {
+  if (B < 0 || H <= 0 || Sq <= 0 || Sk <= 0) return 0;
+  return static_cast<long>(B) * H * sc_rows(Sq) * sc_pitch(Sk);
+}
+
+int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
+                 int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
+                 vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !o || !lse || (bias && !bias_strides)) return VQA_ERR_NULL;
   AttnDims d{B, H, Sq, Sk, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], strides[6],
@@ -761,12 +730,14 @@ int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bi
   }
   const int rc = check_attn(q, k, v, d);
   if (rc != VQA_OK) return rc;
-  if (!aligned16(o)) return VQA_ERR_ALIGN;
+  if (!aligned16(o) || !aligned16(scores)) return VQA_ERR_ALIGN;
   if (B == 0) return VQA_OK;
   const dim3 grid(static_cast<unsigned>(((Sq + 127) / 128) * H * B));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bias) attn_fwd_kernel<true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
-  else attn_fwd_kernel<false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, d);
+  if (bias && scores) attn_fwd_kernel<true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
+  else if (bias) attn_fwd_kernel<true, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
+  else if (scores) attn_fwd_kernel<false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
+  else attn_fwd_kernel<false, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
   return launch_status();
 }
 
@@ -777,9 +748,9 @@ long vqa_attn_bwd_ws_floats(int B, int H, int Sq, int Sk) {
 
 /* grad_strides: 12 longs = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} */
 int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
-                 const float* lse, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B, int H, int Sq,
-                 int Sk, const long* strides, const long* bias_strides, const long* grad_strides, float scale,
-                 vqa_stream_t stream) {
+                 const float* lse, const float* scores, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B,
+                 int H, int Sq, int Sk, const long* strides, const long* bias_strides, const long* grad_strides,
+                 float scale, vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !grad_strides || !o || !go || !lse || !delta || !dq || !dk || !dv || (bias && !bias_strides))
     return VQA_ERR_NULL;
@@ -798,10 +769,12 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
   long any = 0;
   for (int i = 0; i < 12; ++i) any |= grad_strides[i];
   if (any & 3) return VQA_ERR_SHAPE;
-  if (!aligned16(o) || !aligned16(go) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(ds_ws))
+  if (!aligned16(o) || !aligned16(go) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(ds_ws) ||
+      !aligned16(scores))
     return VQA_ERR_ALIGN;
-  // the dS path addresses a (batch, head) slab of the workspace with 32-bit lane offsets
-  if (ds_ws && ds_rows(Sk) * ds_pitch(Sq) >= 2147483647L) return VQA_ERR_SHAPE;
+  // the dS path addresses a (batch, head) slab of either workspace with 32-bit lane offsets
+  if (ds_ws && (ds_rows(Sk) * ds_pitch(Sq) >= 2147483647L || sc_rows(Sq) * sc_pitch(Sk) >= 2147483647L))
+    return VQA_ERR_SHAPE;
   if (B == 0) return VQA_OK;
   const long* g = grad_strides;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -811,23 +784,35 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
     const long blocks = (n_rows + kBlock / 16 - 1) / (kBlock / 16);
     if (blocks > 2147483647L) return VQA_ERR_SHAPE;
     attn_delta_kernel<<<dim3(static_cast<unsigned>(blocks)), kBlock, 0, st>>>(o, go, delta, d, g[0], g[1], g[2]);
-    if (bias)
-      attn_bwd_dkv_kernel<true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
-                                                             g[9], g[10], g[11], g[0], g[1], g[2], ds_ws);
+    if (scores && bias)                          // saved scores already include the bias
+      attn_bwd_dkv_kernel<true, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                   g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
+                                                                   scores);
+    else if (scores)
+      attn_bwd_dkv_kernel<false, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                    g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
+                                                                    scores);
+    else if (bias)
+      attn_bwd_dkv_kernel<true, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                    g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
+                                                                    nullptr);
     else
-      attn_bwd_dkv_kernel<false, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
-                                                              g[9], g[10], g[11], g[0], g[1], g[2], ds_ws);
+      attn_bwd_dkv_kernel<false, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
+                                                                     g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
+                                                                     ds_ws, nullptr);
     attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
   } else if (bias) {                             // no workspace: 7 products, both kernels recompute the scores
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
                                                      g[2]);
-    attn_bwd_dkv_kernel<true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
-                                                            g[9], g[10], g[11], g[0], g[1], g[2], nullptr);
+    attn_bwd_dkv_kernel<true, false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                   g[8], g[9], g[10], g[11], g[0], g[1], g[2], nullptr,
+                                                                   nullptr);
   } else {
     attn_bwd_dq_kernel<false><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0],
                                                       g[1], g[2]);
-    attn_bwd_dkv_kernel<false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7], g[8],
-                                                             g[9], g[10], g[11], g[0], g[1], g[2], nullptr);
+    attn_bwd_dkv_kernel<false, false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                    g[8], g[9], g[10], g[11], g[0], g[1], g[2], nullptr,
+                                                                    nullptr);
   }
   return launch_status();
 }
