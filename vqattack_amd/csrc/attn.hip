@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     return t;
   };
   f32x16 bcur = {0};
-  if (kInit && active) bcur = load_bias(0);
+  if (kInit && !FROM_SCORES && active) bcur = load_bias(0);
   {
     const TileRegs tq = load_tile_clamped(qb, d.q_ss, 0, d.Sq), tg = load_tile_clamped(gb, go_ss, 0, d.Sq);
     float rl, rd;
@@ -619,7 +619,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     }
     if (active) {
       f32x16 bnext = {0};
-      if (kInit && more) bnext = load_bias(q0 + kTile);
+      if (FROM_SCORES) bcur = load_bias(q0);     // needed only after the dP chain below: no tile-ahead prefetch, 16
+      else if (kInit && more) bnext = load_bias(q0 + kTile);                                   // registers fewer
       __builtin_amdgcn_sched_barrier(0);
       f32x16 st = bcur, dp = {0};
       if (FROM_SCORES) {
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
         dk0 = mfma(qq[0], dp[i], dk0);
         dk1 = mfma(qq[1], dp[i], dk1);
       }
-      bcur = bnext;
+      if (!FROM_SCORES) bcur = bnext;
     }
     if (more) {
       store_tile_interleaved(Qbuf[(qt + 1) & 1], tq, d.scale);
