@@ -7,6 +7,11 @@ dimension, e.g. the three slices of a packed ``qkv`` projection -- and an option
 transformer block is free.  The white boxes' ``Attention.forward`` (reference: ``vlmo/modules/multiway_transformer.py:
 88-118``) is a callee of the attack's hot path; this replaces ``F.scaled_dot_product_attention`` there (same math, exact
 fp32 products on ``v_mfma_f32_32x32x2_f32``).  There is no CPU path.
+
+Backward: deterministic (no float atomics).  A forward whose inputs require a gradient also saves its pre-softmax scores
+(``SCORES_LIMIT``), and the backward keeps dS in a transient workspace (``DS_WORKSPACE_LIMIT``): 4 matrix products
+instead of the 7 of the workspace-free form, which remains the fallback above the limits.  The bias is frozen (no
+gradient).  A query row whose keys are all masked with ``-inf`` yields NaN, as the library's attention does.
 """
 import ctypes
 
