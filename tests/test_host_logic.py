@@ -88,3 +88,28 @@ def test_dropin_module_paths(flavor):
         sys.path.remove(root)
         for name in [m for m in sys.modules if m == "cleverhans" or m.startswith("cleverhans.")]:
             del sys.modules[name]
+
+
+def test_attention_bias_layout_decision():
+    """Which bias tensors the attention kernels may read in place (rows readable to ceil32(Sk), aligned strides) and
+    which must be copied into padded rows first -- the rule of `attention._bias_layout`, on host tensors."""
+    import torch
+    from vqattack_amd import attention
+
+    s = 587
+    slab = torch.zeros(1, 12, s, 608)                       # what FrozenVlmo.attention_bias builds: rows padded to 32
+    view, ok = attention._bias_layout(slab[..., :s].expand(64, -1, -1, -1), s)
+    assert ok and view.shape == (1, 12, s, s) and view.data_ptr() == slab.data_ptr()
+    _, ok = attention._bias_layout(torch.zeros(1, 12, s, s), s)          # dense rows of 587 floats: no room, odd pitch
+    assert not ok
+    _, ok = attention._bias_layout(torch.zeros(2, 3, 64, 64), 64)        # Sk a multiple of 32: dense rows are fine
+    assert ok
+    tight = torch.zeros(1, 1, 4, 96)[..., :70]                           # pitch 96 = ceil32(70): exactly enough room
+    assert attention._bias_layout(tight, 70)[1]
+    short = torch.zeros(1, 1, 4, 80)[..., :70]                           # last row ends 16 floats early
+    assert not attention._bias_layout(short, 70)[1]
+    pad_mask = torch.zeros(8, 1, 1, 40).expand(8, 12, 40, 40)            # key padding broadcast over heads and rows
+    view, ok = attention._bias_layout(pad_mask, 40)
+    assert view.shape == (8, 1, 1, 40) and not ok                        # 40-float rows: copied, but only 8 of them
+    with pytest.raises(ValueError):
+        attention._bias_layout(torch.zeros(1, 1, 4, 33), 40)

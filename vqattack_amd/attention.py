@@ -44,22 +44,35 @@ def _bias_view(bias, b, h, sq, sk):
         return None, None
     if bias.dtype != torch.float32 or not bias.is_cuda:
         raise TypeError("bias must be a float32 HIP tensor")
+    bias, in_place = _bias_layout(bias, sk)
+    if not in_place:
+        store = torch.zeros(tuple(bias.shape[:-1]) + ((sk + 31) // 32 * 32,), dtype=torch.float32, device=bias.device)
+        store[..., :sk] = bias
+        bias = store[..., :sk]
+    bias = bias.expand(b, h, sq, sk)
+    return bias, (bias.stride(0), bias.stride(1), bias.stride(2))
+
+
+def _bias_layout(bias, sk):
+    """(bias as 4-d with its broadcast dimensions collapsed to size 1, whether the kernels can read it in place).
+
+    In place needs: unit key stride, 16-byte aligned base, every non-broadcast leading stride a non-negative multiple
+    of 4 floats, and ceil32(Sk) floats inside the storage from the start of the LAST row (rows are consecutive in
+    memory, so every earlier row then has them too).  Device-independent: checked on CPU tensors in
+    tests/test_host_logic.py."""
     while bias.dim() < 4:
         bias = bias.unsqueeze(0)
-    if bias.shape[-1] != sk:
-        raise ValueError("bias must have Sk = {} entries in its last dimension, got {}".format(sk, bias.shape[-1]))
+    if bias.dim() != 4 or bias.shape[-1] != sk:
+        raise ValueError("bias must be broadcastable to (B, H, Sq, Sk = {}), got {}".format(sk, tuple(bias.shape)))
     # broadcast (stride-0) dimensions are collapsed first, so that a copy, if one is needed, stays small
     bias = bias[tuple(slice(0, 1) if st == 0 else slice(None) for st in bias.stride()[:-1])]
     pad = (sk + 31) // 32 * 32
     last_row = bias.storage_offset() + sum((n - 1) * st for n, st in zip(bias.shape[:-1], bias.stride()[:-1]))
     room = last_row + pad <= bias.untyped_storage().nbytes() // 4
     lead = [st for st, n in zip(bias.stride()[:-1], bias.shape[:-1]) if n > 1]
-    if bias.stride(-1) != 1 or not room or any(st % 4 or st < 0 for st in lead) or bias.data_ptr() % 16:
-        store = torch.zeros(tuple(bias.shape[:-1]) + (pad,), dtype=torch.float32, device=bias.device)
-        store[..., :sk] = bias
-        bias = store[..., :sk]
-    bias = bias.expand(b, h, sq, sk)
-    return bias, (bias.stride(0), bias.stride(1), bias.stride(2))
+    in_place = (bias.stride(-1) == 1 and room and not any(st % 4 or st < 0 for st in lead)
+                and bias.data_ptr() % 16 == 0)
+    return bias, in_place
 
 
 def _longs(vals):
