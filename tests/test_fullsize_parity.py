@@ -149,3 +149,23 @@ def test_vlmo_large_joint_attack_matches_cpu_oracle():
     _compare(res.adv_images[0].cpu(), adv[0].detach(), budget + words, full_attack=False)
     for got, want in zip(res.loss_lists, losses):
         np.testing.assert_allclose(got, want, rtol=1e-4)
+
+
+def test_vlmo_base_attack_is_bitwise_reproducible():
+    """Two runs of the same attack give the same bits: no kernel of the path accumulates with float atomics (loss fold
+    in index order, two-stage per-sample reductions, attention backward without atomics), so a result can be compared
+    across runs, ranks and batch compositions."""
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_base
+    steps = 6
+    model = FrozenVlmo(vlmo_base(384), seed=0).to(DEV)
+    ids, masks, img, eta = _inputs([5, 9, 7], 40)
+    runs = []
+    for _ in range(2):
+        attack = BatchedVQAttack(VlmoAttackAdapters(model), "vlmo", model.embedding_tables(),
+                                 AttackConfig(budget=steps, sanity_checks=True))
+        res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV),
+                                  torch.zeros_like(ids, dtype=torch.bool).to(DEV), init_eta=eta.to(DEV))
+        runs.append((res.adv_images.clone(), [list(x) for x in res.loss_lists]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1]
