@@ -234,3 +234,65 @@ def test_batched_dual_attack_with_ragged_mlm_tasks_matches_per_sample_oracle(fla
             want_ids, _ = ts.encode_words(want_words, max_len or 25, max_len, ())
             assert got_mlm == want_ids[:mlm_len]
     assert n_changed >= 1, "the case should exercise at least one accepted substitution"
+
+
+@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
+def test_mixed_batch_of_feature_and_dual_samples_matches_per_sample_oracle(flavor):
+    """``attack_mixed`` with per-sample loss modes: sample 0 feature loss with 2 words, sample 1 dual loss (3-d labels,
+    K = 2) with 2 words, sample 2 dual loss (K = 3) without substitutable words -- three different step sequences in one
+    white-box batch -- against the batch-1 CPU oracle loop of each sample."""
+    from oracle import text_scoring as ts
+    from vqattack_amd.attack import mlm_task
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    cpu_model, gpu_model, adapters_cls, ref_cls, cfg = _build(flavor)
+    g = torch.Generator().manual_seed(41)
+    images = torch.empty(3, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(images).uniform_(-0.125, 0.125, generator=g)
+    masks = (IDS != 0).long()
+    att = ATTACKABLE.clone()
+    att[2] = False
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    body = [[(int(t),) for t in IDS[s].tolist() if t not in (0, 101, 102)] for s in range(3)]
+    answers = [None, (7002,), (7003,)]
+    paras = [None, body[1][:2] + [answers[1]] + [(8123,)], [answers[2]] + body[2] + [(8456,), (8457,)]]
+    alts = [None, [(7102,)], [(7103,), (7203,)]]
+    max_len = cfg.max_text_len if flavor == "vlmo" else None
+    tasks, oracle_tasks = [None], [None]
+    for s in (1, 2):
+        correct = [[answers[s]]] + [[a] for a in alts[s]]
+        same = [True] + [False] * len(alts[s])
+        tasks.append(mlm_task.build_mlm_task([answers[s]], correct, same, paras[s], [], flavor, max_len=max_len))
+        assert tasks[-1].old_alg == 0
+        ot = ts.build_mlm_task([answers[s]], correct, same, paras[s], [], flavor)
+        if flavor == "vlmo":
+            ot["text_ids_mlm"], ot["text_mask_mlm"] = ts.encode_words(ot["list_words"], max_len, max_len)
+            ot["mlm_labels"] = [row[:max_len] for row in ot["mlm_labels"]]
+        ot["tail"] = ()
+        oracle_tasks.append(ot)
+    attack = BatchedVQAttack(adapters_cls(gpu_model), flavor, gpu_model.embedding_tables(),
+                             AttackConfig(budget=12, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    logits = attack.adapters.mlm_logits(IDS.to(DEV), masks.to(DEV))
+    proposals = text_update.propose_candidates(logits, IDS, att, threshold=0)
+    res = attack.attack_mixed(images.to(DEV), IDS.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals, tasks=tasks)
+    assert res.gradient_steps == 14 + 14 + 12
+    assert res.adv_text_ids.shape == IDS.shape
+    n_changed = 0
+    for s in range(3):
+        n = int(masks[s].sum()) if flavor == "albef" else IDS.shape[1]
+        if flavor == "vlmo":            # the oracle loop re-encodes the paraphrase at 40: keep this model's text length
+            orig = ts.encode_words
+            ts.encode_words = lambda words, _ml, _pad, tail=(): orig(words, max_len, max_len, tail)
+        try:
+            adv, ids, _ = attack_loop.attack_one(ref_cls, cpu_model, flavor, images[s:s + 1], IDS[s:s + 1, :n],
+                                                 masks[s:s + 1, :n], proposals[s] if proposals[s] else None, sim,
+                                                 init_eta=eta[s:s + 1], budget=12, sim_threshold=0.3,
+                                                 task=oracle_tasks[s])
+        finally:
+            if flavor == "vlmo":
+                ts.encode_words = orig
+        assert res.adv_text_ids[s, :n].cpu().tolist() == ids[0].tolist(), (flavor, s)
+        n_changed += int((ids[0] != IDS[s, :n]).sum())
+        same_px = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
+        assert same_px >= 0.99, (flavor, s, same_px)
+    assert n_changed >= 1

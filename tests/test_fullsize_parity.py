@@ -151,6 +151,178 @@ def test_vlmo_large_joint_attack_matches_cpu_oracle():
         np.testing.assert_allclose(got, want, rtol=1e-4)
 
 
+def _sum_by_step(per_sample_lists):
+    """Per-sample loss lists (one value per white-box step of that sample) -> per global step sums (a batch's losses)."""
+    out = np.zeros(max(len(x) for x in per_sample_lists))
+    for x in per_sample_lists:
+        out[:len(x)] += x
+    return out
+
+
+def test_vlmo_base_ragged_batch_with_mixed_schedules_matches_per_sample_oracle():
+    """BASELINE configs[1]/[3] shape at batch > 1 -- the one place where the product's semantics (batched, row weights,
+    trimmed padding, per-sample schedules in one batch) differ from the batch-1 reference (vlmo_module.py:1438-1444 ``[0]``
+    indexing): four questions of 3 / 6 / 9 / 12 words (padding trimmed 617 -> 591 tokens, row weights 0 / 1 / 2), one of
+    them with 2 substitutable words, attacked as ONE batch through ``attack_mixed``; every sample against its own batch-1
+    CPU oracle loop with reference-style packing (vlmo_module.py:1387-1446, 1943-2055)."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import VlmoRefAdapters
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_base
+    budget, words = 6, 2
+    cpu_model = FrozenVlmo(vlmo_base(384), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, img, eta = _inputs([3, 6, 9, 12], 40, seed=2)
+    att = torch.zeros_like(ids, dtype=torch.bool)
+    att[2, 2:2 + words] = True
+    adapters = VlmoAttackAdapters(gpu_model)
+    proposals = text_update.propose_candidates(adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att, threshold=0)
+    assert [len(p) for p in proposals] == [0, 0, words, 0]
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(adapters, "vlmo", gpu_model.embedding_tables(),
+                             AttackConfig(budget=budget, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    res = attack.attack_mixed(img.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    assert res.gradient_steps == 4 * budget + words
+    per_sample, oracle_adv, oracle_ids = [], [], []
+    for s in range(4):
+        adv, new_ids, losses = attack_loop.attack_one(VlmoRefAdapters, cpu_model, "vlmo", img[s:s + 1], ids[s:s + 1],
+                                                      masks[s:s + 1], proposals[s] if proposals[s] else None, sim,
+                                                      init_eta=eta[s:s + 1], budget=budget, sim_threshold=0.3)
+        assert res.adv_text_ids[s].cpu().tolist() == new_ids[0].tolist(), s
+        _compare(res.adv_images[s].cpu(), adv[0].detach(), budget + words, full_attack=False)
+        oracle_adv.append(adv.detach())
+        oracle_ids.append(new_ids)
+        if s != 2:
+            per_sample.append([v for block in losses for v in block])
+    assert int((res.adv_text_ids[2].cpu() != ids[2]).sum()) >= 1, "the case should exercise an accepted substitution"
+    # attack-success bits (vlmo_module.py:2063-2091) at base size: product attack + batched scorer on the device vs oracle
+    # attack + per-question CPU scorer (oracle/blackbox_ref.py) over the same fine-tuned black box
+    from oracle import blackbox_ref as bb
+    black = FrozenVlmo.finetuned_from(cpu_model, seed=1)
+    with torch.no_grad():
+        def cpu_answers(images, text):
+            out = []
+            for s in range(4):
+                _, states = black.encode(images[s:s + 1], black.text_embeddings(text[s:s + 1]), masks[s:s + 1])
+                out += bb.vlmo_predict(black.vqa_classifier(black.pooled(states)))
+            return out
+        want_clean = cpu_answers(img, ids)
+        want_after = cpu_answers(torch.cat(oracle_adv), torch.cat(oracle_ids))
+    black_gpu = copy.deepcopy(black).to(DEV)
+    got_clean = black_gpu.vqa_answer(img.to(DEV), ids.to(DEV), masks.to(DEV)).cpu().tolist()
+    got_after = black_gpu.vqa_answer(res.adv_images, res.adv_text_ids, masks.to(DEV)).cpu().tolist()
+    del black_gpu
+    assert got_clean == want_clean
+    assert [int(a != c) for a, c in zip(got_after, got_clean)] == [int(a != c) for a, c in zip(want_after, want_clean)]
+    # losses: the oracle loop does not report the loss of a probe step, so the batch trajectory is compared on a second,
+    # image-only run of the same four questions (every step of every sample is then reported on both sides)
+    res2 = attack.attack_mixed(img.to(DEV), ids.to(DEV), masks.to(DEV), torch.zeros_like(att).to(DEV),
+                               init_eta=eta.to(DEV))
+    adv2, _, losses2 = attack_loop.attack_one(VlmoRefAdapters, cpu_model, "vlmo", img[2:3], ids[2:3], masks[2:3], None, sim,
+                                              init_eta=eta[2:3], budget=budget)
+    per_sample.append([v for block in losses2 for v in block])
+    np.testing.assert_allclose(res2.loss_lists[0], _sum_by_step(per_sample), rtol=1e-4)
+    _compare(res2.adv_images[2].cpu(), adv2[0].detach(), budget, full_attack=False)
+
+
+def _dual_tasks(flavor, ids, max_len):
+    """Two dual-loss samples (old_alg == 0): paraphrase = question words + answer word (+ filler); sample 0 with one
+    correct one-piece answer (2-d labels, 1 live label row), sample 1 with a two-piece answer and a second correct answer
+    of the same piece count (3-d labels, K = 2, 2 live label rows)."""
+    from oracle import text_scoring as ts
+    from vqattack_amd.attack import mlm_task
+    tasks, oracle_tasks = [], []
+    for s in range(ids.shape[0]):
+        body = [(int(t),) for t in ids[s].tolist() if t not in (0, 101, 102)]
+        answer = (7001 + s, 7101 + s) if s % 2 else (7001 + s,)      # odd samples: a two-piece answer word -> 2 [MASK]s
+        para = body[:3] + [answer] + [(8100 + s,)]
+        correct = [[answer]] + ([[(7500 + s, 7600 + s)]] if s % 2 else [])
+        same = [True] + [False] * (len(correct) - 1)
+        tasks.append(mlm_task.build_mlm_task([answer], correct, same, para, [], flavor, max_len=max_len))
+        ot = ts.build_mlm_task([answer], correct, same, para, [], flavor)
+        ot["tail"] = ()
+        assert tasks[-1].old_alg == 0 and ot["old_alg"] == 0
+        assert ot["text_ids_mlm"] == tasks[-1].text_ids_mlm and ot["mlm_labels"] == tasks[-1].mlm_labels
+        oracle_tasks.append(ot)
+    return tasks, oracle_tasks
+
+
+@pytest.mark.parametrize("live_rows", [True, False])
+def test_vlmo_base_dual_loss_batch_matches_per_sample_oracle(live_rows):
+    """``old_alg == 0`` at VLMO-base size, batch 2: ``pgd_mlm_attack`` (vlmo_module.py:1448-1529) through the real
+    30 522-word MLM head + the dual loop (projected_gradient_descent.py:153-189), 4 dual iterations (8 white-box
+    gradient steps), 2-d labels on sample 0 and 3-d labels (K = 2) on sample 1, per-sample cross-entropy normalisation.
+    ``live_rows``: the MLM head and ``vqa_ce_rows`` on the live label rows only (default) / on all B x 40 positions with
+    the dead rows skipped inside the kernel -- both must give the batch-1 oracle's trajectory."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import VlmoRefAdapters
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_base
+    budget = 8
+    cpu_model = FrozenVlmo(vlmo_base(384), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, img, eta = _inputs([5, 8], 40, seed=3)
+    tasks, oracle_tasks = _dual_tasks("vlmo", ids, 40)
+    attack = BatchedVQAttack(VlmoAttackAdapters(gpu_model), "vlmo", gpu_model.embedding_tables(),
+                             AttackConfig(budget=budget, sanity_checks=True, live_mlm_rows=live_rows))
+    res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV), torch.zeros_like(ids, dtype=torch.bool).to(DEV),
+                              init_eta=eta.to(DEV), dual=True, tasks=tasks)
+    assert res.gradient_steps == budget and len(res.loss_lists[0]) == budget      # 4 x (feature, MLM)
+    per_sample = []
+    for s in range(2):
+        adv, _, losses = attack_loop.attack_one(VlmoRefAdapters, cpu_model, "vlmo", img[s:s + 1], ids[s:s + 1],
+                                                masks[s:s + 1], None, None, init_eta=eta[s:s + 1], budget=budget,
+                                                task=oracle_tasks[s])
+        _compare(res.adv_images[s].cpu(), adv[0].detach(), budget, full_attack=False)
+        per_sample.append(losses[0])
+    # per_sample=True: the batch's MLM loss is the SUM of the samples' own batch-1 cross entropies
+    np.testing.assert_allclose(res.loss_lists[0], _sum_by_step(per_sample), rtol=2e-4)
+
+
+def test_albef_base_batch_with_substitution_matches_per_sample_oracle():
+    """BASELINE configs[2] shape at batch 2 with one substitutable word per question: the text-embedding gradient comes
+    back through the six cross-attention layers (``pgd_attack_vl`` / ``Gen_feats_from_embeds``, adv_attack.py:208-214,
+    model_pretrain.py:85-104), candidates are scored and accepted on the device, and the second question is padded
+    (ALBEF at batch 1 tokenises without padding, adv_attack.py:113).  Reference loop: adv_attack.py:604-712."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import AlbefRefAdapters
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_base
+    budget = 6                                          # blocks [2, 4] + 1 probe step = 7 white-box gradient steps
+    cpu_model = FrozenAlbef(albef_base(384, mlm_probability=0.0), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, img, eta = _inputs([6, 4], 8, seed=4)
+    att = torch.zeros_like(ids, dtype=torch.bool)
+    att[0, 3] = att[1, 2] = True
+    adapters = AlbefAttackAdapters(gpu_model)
+    proposals = text_update.propose_candidates(adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att, threshold=0)
+    assert [len(p) for p in proposals] == [1, 1]
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(adapters, "albef", gpu_model.embedding_tables(),
+                             AttackConfig(budget=budget, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    assert res.gradient_steps == budget + 1
+    blocks = None
+    n_changed = 0
+    for s in range(2):
+        n = int(masks[s].sum())
+        adv, new_ids, losses = attack_loop.attack_one(AlbefRefAdapters, cpu_model, "albef", img[s:s + 1], ids[s:s + 1, :n],
+                                                      masks[s:s + 1, :n], proposals[s], sim, init_eta=eta[s:s + 1],
+                                                      budget=budget, sim_threshold=0.3)
+        assert res.adv_text_ids[s, :n].cpu().tolist() == new_ids[0].tolist(), s
+        assert res.adv_text_ids[s, n:].cpu().tolist() == ids[s, n:].tolist()
+        n_changed += int((new_ids[0] != ids[s, :n]).sum())
+        _compare(res.adv_images[s].cpu(), adv[0].detach(), budget + 1, full_attack=False)
+        blocks = [np.array(b) for b in losses] if blocks is None else [a + np.array(b) for a, b in zip(blocks, losses)]
+    assert n_changed >= 1, "the case should exercise at least one accepted substitution"
+    for got, want in zip(res.loss_lists, blocks):
+        np.testing.assert_allclose(got, want, rtol=1e-4)
+
+
 def test_vlmo_base_attack_is_bitwise_reproducible():
     """Two runs of the same attack give the same bits: no kernel of the path accumulates with float atomics (loss fold
     in index order, two-stage per-sample reductions, attention backward without atomics), so a result can be compared

@@ -258,3 +258,73 @@ def test_mixed_schedule_batch_equals_reference_loops(gold, flavor):
         same = float((got == want).float().mean())
         assert same >= 0.995, (c["name"], same)
         assert float((got - want).abs().max()) <= 2 * 0.01 * (40 + int(attackable[s].sum())) + 1e-6
+
+
+@pytest.mark.parametrize("flavor", ["albef", "vlmo"])
+def test_mixed_batch_with_dual_loss_samples_equals_reference_loops(gold, flavor):
+    """ALL six loop cases of a flavor -- three feature-loss (``old_alg == 1``) and three dual-loss (``old_alg == 0``: 2-d and
+    3-d MLM labels, with and without substitutable words) samples, six different schedules -- attacked as ONE batch by
+    ``attack_mixed``: prefix scheduling, dual-loss samples alternating feature steps (no projection) and MLM steps on
+    their [MASK]-ed paraphrase inside the shared white-box pass, MLM head and cross entropy at the live label rows only,
+    the paraphrase following the question's substitutions.  Every sample must come out as the reference's own loop code
+    produced it alone (adv_attack.py:428-712; vlmo_module.py:1743-2057)."""
+    z, meta = gold
+    model = build_model(flavor, meta).to(DEV)
+    if flavor == "albef":
+        from vqattack_amd.whitebox.albef import AlbefAttackAdapters as Adapters
+    else:
+        from vqattack_amd.whitebox.vlmo import VlmoAttackAdapters as Adapters
+    cases = meta["loop_" + flavor]["cases"]
+    assert sorted(c["old_alg"] for c in cases) == [0, 0, 0, 1, 1, 1]
+    parts = [_case_inputs(z, meta, flavor, c, model) for c in cases]
+    for p, c in zip(parts, cases):
+        assert p[2].old_alg == c["old_alg"]
+    length = max(p[3].shape[1] for p in parts)
+
+    def pad(t, fill=0):
+        out = torch.full((1, length), fill, dtype=t.dtype)
+        out[:, :t.shape[1]] = t
+        return out
+
+    ids = torch.cat([pad(p[3]) for p in parts]).to(DEV)
+    masks = torch.cat([pad(p[4]) for p in parts]).to(DEV)
+    attackable = torch.cat([pad(p[1]) for p in parts]).to(DEV)
+    proposals = [p[0][0] for p in parts]
+    tasks = [p[2] for p in parts]
+    images = torch.cat([torch.from_numpy(z[c["key"] + "_image"]) for c in cases]).to(DEV)
+    eta = torch.cat([torch.from_numpy(z[c["key"] + "_eta"]) for c in cases]).to(DEV)
+    sim = text_update.BagOfEmbeddingsSimilarity(table=z["use_table"])
+    attack = BatchedVQAttack(Adapters(model), flavor, model.embedding_tables(), AttackConfig(sanity_checks=True),
+                             similarity_fn=sim)
+    res = attack.attack_mixed(images, ids, masks, attackable, init_eta=eta, proposals=proposals, tasks=tasks)
+    assert res.gradient_steps == sum(40 + int(a.sum()) for a in attackable)
+    assert res.adv_text_ids.shape == ids.shape
+    n_changed = 0
+    for s, c in enumerate(cases):
+        n = len(c["adv_text_ids"])
+        assert res.adv_text_ids[s, :n].tolist() == c["adv_text_ids"], (c["name"], c["adv_text"])
+        n_changed += sum(int(a != b) for a, b in zip(c["adv_text_ids"], c["text_ids"]))
+        want = torch.from_numpy(z[c["key"] + "_adv"])[0]
+        got = res.adv_images[s].cpu()
+        same = float((got == want).float().mean())
+        assert same >= 0.995, (c["name"], same)
+        assert float((got - want).abs().max()) <= 2 * 0.01 * (40 + int(attackable[s].sum())) + 1e-6
+    assert n_changed >= 2
+    # the loss trajectory of the batch = the sum of the samples' own trajectories (feature losses are per-sample sums, MLM
+    # cross entropies are normalised per sample); global step t is every sample's own step t.  The reference's loop does
+    # not report the loss of a probe step (pgd_vl returns the text gradient instead), so steps where any sample probes
+    # are left out.
+    got_losses = np.array(res.loss_lists[0])
+    want_losses = np.zeros_like(got_losses)
+    comparable = np.ones(len(got_losses), dtype=bool)
+    for s, c in enumerate(cases):
+        kinds = BatchedVQAttack._step_kinds(int(attackable[s].sum()), 40, c["old_alg"] == 0)
+        flat = iter(v for call in c["pgd_calls"] for v in call["losses"])
+        for t, (_, is_probe) in enumerate(kinds):
+            if is_probe:
+                comparable[t] = False
+            else:
+                want_losses[t] += next(flat)
+        assert next(flat, None) is None
+    assert comparable.sum() >= 20
+    np.testing.assert_allclose(got_losses[comparable], want_losses[comparable], rtol=2e-4, atol=2e-5)

@@ -137,3 +137,22 @@ def apply_substitutions(words_mlm: List[Word], ops: Sequence[Tuple[int, int]]) -
             if w == (old,):
                 words_mlm[i] = (new,)
     return words_mlm
+
+
+def live_label_rows(labels):
+    """Positions of a batch's MLM labels that are a target in at least one label set, as a rectangular index.
+
+    ``labels``: int64 tensor (B, L) or (B, K, L) with ``IGNORE`` everywhere except the [MASK]-ed answer pieces
+    (adv_attack.py:433-558) -- typically 1-3 of the L positions.  Returns ``(rows (B, W) int64, compact labels (B, W) or
+    (B, K, W))`` with W = the largest number of live positions of a sample: a sample's live positions in ascending
+    order, padded with dead positions of the same sample (whose labels are all ``IGNORE``, so they add nothing to the
+    loss and the cross-entropy kernel does not even load their logits).  A white box that evaluates its MLM head on
+    ``states[b, rows[b]]`` only, against the compact labels, computes the same per-sample losses and gradients as the
+    dense (B, L, V) form without producing the B x L x V logits and their gradient.  One host read (W)."""
+    import torch
+    live = (labels != IGNORE) if labels.dim() == 2 else (labels != IGNORE).any(dim=1)
+    width = max(int(live.sum(dim=1).max().item()), 1) if live.numel() else 1
+    order = torch.argsort((~live).to(torch.int32), dim=1, stable=True)[:, :width]          # live first, ascending
+    if labels.dim() == 2:
+        return order, torch.gather(labels, 1, order)
+    return order, torch.gather(labels, 2, order.unsqueeze(1).expand(-1, labels.shape[1], -1))

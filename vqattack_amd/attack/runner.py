@@ -20,6 +20,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from .. import attacks, dropin, layout, ops
 from ..features import LayerFeatures
@@ -40,6 +41,7 @@ class AttackConfig:
     sim_threshold: float = text_update.SIM_THRESHOLD   # adv_attack.py:303
     use_graph: bool = False            # replay PGD iterations from a hipGraph (small, launch-bound batches)
     patch_layout: bool = False         # keep the PGD state patch-major (layout.py); measured neutral end to end, see DESIGN
+    live_mlm_rows: bool = True         # dual loss: MLM head + cross entropy at the live label rows only (False: dense B x L)
 
 
 @dataclass
@@ -151,6 +153,14 @@ class BatchedVQAttack:
         if dual and mlm_labels is not None and tlen is not None and tlen < mlm_labels.shape[-1] and \
                 bool((mlm_labels[..., tlen:] != mlm_task.IGNORE).any()):
             raise ValueError("MLM labels beyond the batch's text length {} must be ignore_index".format(tlen))
+        if hasattr(a, "set_mlm_rows"):
+            # live-rows form of the MLM closure: the head runs, and the cross entropy is taken, at the label positions that
+            # are targets only (the [MASK]-ed answer pieces, adv_attack.py:433-558) -- not over all B x L positions
+            if dual and mlm_labels is not None and c.live_mlm_rows:
+                live_rows, mlm_labels = mlm_task.live_label_rows(mlm_labels)
+                a.set_mlm_rows(live_rows)
+            else:
+                a.set_mlm_rows(None)
         targets = a.gen_ori_feats(images)
         res = BatchResult(adv_images=adv, adv_text_ids=adv_ids)
         first_time = 0 if c.random_start else 1
@@ -203,6 +213,8 @@ class BatchedVQAttack:
                                 mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in per])
                                 ids_s = tasks[s].reencode()
                                 mlm_ids[s, :len(ids_s)] = torch.tensor(ids_s, device=dev, dtype=mlm_ids.dtype)
+        if hasattr(a, "set_mlm_rows"):
+            a.set_mlm_rows(None)                 # the adapters' MLM closure is dense again for any other caller
         res.substitutions = [text_update.substitution_lists(*r) for r in rounds]     # one host read, after the attack
         res.adv_images, res.adv_text_ids, res.adv_text_ids_mlm = restore(adv), adv_ids, mlm_ids
         return res
@@ -218,10 +230,24 @@ class BatchedVQAttack:
         return layout.to_patches(images, patch), eta, (lambda t: layout.from_patches(t, patch, h, w, ch))
 
     # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _step_kinds(n_words, budget, dual):
+        """A sample's own sequence of white-box gradient steps as (kind, is_probe) pairs.  Kinds: ``F`` feature-loss step
+        followed by the eps-ball projection (every step of an ``old_alg == 1`` sample, and every probe); ``N`` feature
+        step WITHOUT projection and ``M`` MLM step with projection -- the two halves of one dual-loss iteration
+        (projected_gradient_descent.py:153-189), ``int(iter / 2)`` iterations per block (adv_attack.py:614-619,670-676)."""
+        blocks = iter_schedule(n_words, budget) or [budget]
+        seq = []
+        for j, blen in enumerate(blocks):
+            seq += [("N", False), ("M", False)] * (blen // 2) if dual else [("F", False)] * blen
+            if j < len(blocks) - 1:
+                seq.append(("F", True))
+        return seq
+
     @torch.no_grad()
     def attack_mixed(self, images, text_ids, text_masks, attackable, mlm_logits_fn=None, init_eta=None,
-                     proposals=None):
-        """Feature-loss joint attack of a batch whose samples have DIFFERENT numbers of attackable words.
+                     proposals=None, tasks=None):
+        """Joint attack of a batch whose samples have DIFFERENT numbers of attackable words and DIFFERENT loss modes.
 
         A sample with ``w`` substitutable words is, end to end, one sequence of ``budget + w`` L-inf steps whose text
         changes after each of its probe steps (the reference's per-block ``projected_gradient_descent`` calls restart
@@ -230,29 +256,60 @@ class BatchedVQAttack:
         of the white-box batch instead of being masked), every step takes the image+text-embedding gradient, and a
         sample's word substitution fires right after its own probe steps.  Per-sample results equal ``attack_batch`` on
         schedule-pure buckets (tests/test_attack_batched_parity.py).
+
+        ``tasks`` (optional, one ``mlm_task.MlmTask`` or None per sample): samples whose task has ``old_alg == 0`` run the
+        reference's dual-loss blocks -- their steps alternate between a feature step without projection and an MLM step
+        on the [MASK]-ed paraphrase (``_step_kinds``).  All samples still share ONE white-box pass per global step
+        (``adapters.pgd_attack_mixed``): a sample at an MLM step is run with its paraphrase as text, its feature rows
+        weigh 0 and its MLM head is evaluated at its live label rows only; the fused image update is launched per run of
+        consecutive samples of one kind.  The paraphrase follows the question's substitutions (``update_mlm_text``).
         """
         c, a = self.cfg, self.adapters
         if c.norm != np.inf:
-            raise ValueError("attack_mixed implements the L-inf feature-loss attack")
-        dev, b = images.device, images.shape[0]
+            raise ValueError("attack_mixed implements the L-inf attack")
+        dev, b, text_len = images.device, images.shape[0], text_ids.shape[1]
         images, init_eta, restore = self._enter_layout(images, init_eta)
-        n_words = attackable.sum(dim=1).tolist()
-        total = [c.budget + int(w) for w in n_words]
-        order = sorted(range(b), key=lambda s: -total[s])                 # longest first: active set = prefix
+        n_words = [int(w) for w in attackable.sum(dim=1).tolist()]
+        is_dual = [tasks is not None and tasks[s] is not None and tasks[s].old_alg == 0 for s in range(b)]
+        kinds = [self._step_kinds(n_words[s], c.budget, is_dual[s]) for s in range(b)]
+        # longest first: the active set is a prefix; equal lengths keep the loss modes together (fewer update launches)
+        order = sorted(range(b), key=lambda s: (-len(kinds[s]), is_dual[s]))
         perm = torch.tensor(order, device=dev)
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(b, device=dev)
         images, text_ids, text_masks, attackable = images[perm], text_ids[perm], text_masks[perm], attackable[perm]
         if init_eta is not None:
             init_eta = init_eta[perm]
-        total = [total[s] for s in order]
-        probes = []                                                       # per sample: global step indices of its probes
-        for s in order:
-            blocks, at, mine = iter_schedule(int(n_words[s]), c.budget), 0, set()
-            for j, blen in enumerate(blocks[:-1]):
-                at += blen
-                mine.add(at + j)
-            probes.append(mine)
+        kinds = [kinds[s] for s in order]
+        is_dual = [is_dual[s] for s in order]
+        total = [len(k) for k in kinds]
+        any_dual = any(is_dual)
+        if any_dual and not hasattr(a, "pgd_attack_mixed"):
+            raise ValueError("dual-loss samples in attack_mixed need adapters with pgd_attack_mixed()")
+        # ---- MLM side of the dual-loss samples: paraphrase ids / masks, labels, live label rows (fixed for the attack)
+        mlm_ids = mlm_mask = labels_live = emb_mlm = None
+        if any_dual:
+            tasks = [mlm_task.MlmTask(**vars(tasks[s])) if is_dual[i] else None for i, s in enumerate(order)]
+            for t in tasks:
+                if t is not None:
+                    t.words_mlm = list(t.words_mlm)                       # private copies: update_mlm_text edits them
+            width = max([text_ids.shape[1]] + [len(t.text_ids_mlm) for t in tasks if t is not None])
+            if width > text_ids.shape[1]:          # ALBEF encodes a paraphrase at its own length (padding='longest')
+                grow = (0, width - text_ids.shape[1])
+                text_ids, text_masks = F.pad(text_ids, grow), F.pad(text_masks, grow)
+                attackable = F.pad(attackable, grow)
+            mlm_ids, mlm_mask = text_ids.clone(), text_masks.clone()
+            sets = [[] if t is None else (t.mlm_labels if isinstance(t.mlm_labels[0], list) else [t.mlm_labels])
+                    for t in tasks]
+            k = max(len(x) for x in sets)
+            labels = torch.full((b, k, width), mlm_task.IGNORE, dtype=torch.int64)
+            for s, t in enumerate(tasks):
+                if t is None:
+                    continue
+                self._write_mlm_row(mlm_ids, mlm_mask, s, t)
+                for j, row in enumerate(sets[s]):
+                    labels[s, j, :len(row)] = torch.tensor(row)
+            labels = (labels[:, 0] if k == 1 else labels).to(dev)
         if proposals is None:
             fn = mlm_logits_fn or getattr(a, "mlm_logits", None)
             proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
@@ -260,8 +317,15 @@ class BatchedVQAttack:
         else:
             proposals = [proposals[s] for s in order]
         plan = text_update.CandidatePlan(proposals, dev)
-        a.set_text(text_ids, text_masks)
+        a.set_text(text_ids, text_masks, text_ids_mlm=mlm_ids, text_mask_mlm=mlm_mask)
         pinned = getattr(a, "_tlen", None)                                # token layout of the targets
+        if any_dual:
+            if getattr(a, "trim_padding", False) and pinned is not None and pinned < labels.shape[-1] and \
+                    bool((labels[..., pinned:] != mlm_task.IGNORE).any()):
+                raise ValueError("MLM labels beyond the batch's text length {} must be ignore_index".format(pinned))
+            rows, labels_live = mlm_task.live_label_rows(labels)
+            a.set_mlm_rows(rows)
+            emb_mlm = ops.embed_tokens(self.tables, mlm_ids)
         targets = a.gen_ori_feats(images)
         e_ori = ops.embed_tokens(self.tables, text_ids)
         adv_emb = e_ori.clone()
@@ -276,21 +340,59 @@ class BatchedVQAttack:
         losses = torch.zeros(max(total), dtype=torch.float32, device=dev)
         ws = ops.Workspace()
         res = BatchResult(adv_images=cur, adv_text_ids=adv_ids)
-        n_act_prev = None
+        text_key, text_cache, version = None, {}, 0                       # (active samples, who is at an MLM step, text edit)
         for t in range(max(total)):
             n_act = sum(1 for x in total if x > t)
-            if n_act != n_act_prev:
-                a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
+            now = [kinds[s][t][0] for s in range(n_act)]
+            at_mlm = tuple(s for s in range(n_act) if now[s] == "M")
+            key = (n_act, at_mlm, version)
+            if key != text_key:
+                if key in text_cache:
+                    a.load_text(text_cache[key])
+                else:
+                    ids_t, masks_t = adv_ids[:n_act], text_masks[:n_act]
+                    if at_mlm:
+                        sel = torch.tensor(at_mlm, device=dev)
+                        ids_t, masks_t = ids_t.clone(), masks_t.clone()
+                        ids_t[sel], masks_t[sel] = mlm_ids[sel], mlm_mask[sel]
+                    a.set_text(ids_t, masks_t, text_len=pinned)
+                    if any_dual:                                          # dual iterations alternate between two texts
+                        if len(text_cache) >= 2:
+                            text_cache.pop(next(iter(text_cache)))
+                        text_cache[key] = a.save_text()
+                if any_dual:
+                    a.set_mlm_samples(torch.tensor(at_mlm, device=dev) if at_mlm else None)
                 y = [v.rows(n_act) if isinstance(v, LayerFeatures) else (None if v is None else v[:n_act])
                      for v in self._y_feature(targets)]
-                n_act_prev = n_act
+                text_key = key
             leaf_img = cur[:n_act].detach().requires_grad_(True)
-            leaf_txt = adv_emb[:n_act].detach().requires_grad_(True)
-            attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1, self.flavor,
-                                   False, attacks._LossSlot(losses, t), vl=True, ws=ws)
-            ops.linf_step(cur[:n_act], leaf_img.grad, images[:n_act], c.eps_iter, c.eps, c.clip_min, c.clip_max,
-                          out=cur[:n_act])                                # in place: finished samples stay untouched
-            firing = [s for s in range(n_act) if t in probes[s]]
+            emb_t = adv_emb[:n_act]
+            if at_mlm:
+                emb_t = emb_t.clone()
+                sel = torch.tensor(at_mlm, device=dev)
+                emb_t[sel] = emb_mlm[sel]
+            leaf_txt = emb_t.detach().requires_grad_(True)
+            slot = attacks._LossSlot(losses, t)
+            if any_dual:
+                attacks._mixed_loss_and_grad(a.pgd_attack_mixed, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y),
+                                             self.flavor, slot, ws=ws, flag=flag,
+                                             mlm_labels=labels_live[torch.tensor(at_mlm, device=dev)] if at_mlm else None)
+            else:
+                attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1,
+                                       self.flavor, False, slot, vl=True, ws=ws)
+            grad = attacks._grad_of(leaf_img)
+            lo = 0
+            while lo < n_act:                                             # one fused update per run of equal kinds
+                hi = lo + 1
+                while hi < n_act and (now[hi] == "N") == (now[lo] == "N"):
+                    hi += 1
+                if now[lo] == "N":      # first half of a dual iteration: no projection in between (pgd :155-188)
+                    ops.linf_fgm(cur[lo:hi], grad[lo:hi], c.eps_iter, c.clip_min, c.clip_max, out=cur[lo:hi])
+                else:                   # in place: finished samples stay untouched
+                    ops.linf_step(cur[lo:hi], grad[lo:hi], images[lo:hi], c.eps_iter, c.eps, c.clip_min, c.clip_max,
+                                  out=cur[lo:hi])
+                lo = hi
+            firing = [s for s in range(n_act) if kinds[s][t][1]]
             if firing:
                 sub = plan.restricted_to(firing)
                 scores = text_update.score_plan(self.tables, e_ori[:n_act], leaf_txt.grad, sub)
@@ -299,11 +401,38 @@ class BatchedVQAttack:
                                                         self.similarity_fn, c.sim_threshold)   # in place, on the device
                 rounds.append((prev, new_id, rank))
                 ops.embed_tokens(self.tables, adv_ids, out=adv_emb)
-                a.set_text(adv_ids[:n_act], text_masks[:n_act], text_len=pinned)
+                version += 1
+                text_cache.clear()
+                if any_dual and any(is_dual[s] for s in firing):          # update_mlm_text (adv_attack.py:334-351)
+                    subs = text_update.substitution_lists(prev, new_id, rank)
+                    changed = False
+                    for s in firing:
+                        if is_dual[s] and subs[s]:
+                            mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in subs[s]])
+                            tasks[s].reencode()
+                            self._write_mlm_row(mlm_ids, mlm_mask, s, tasks[s])
+                            changed = True
+                    if changed:
+                        ops.embed_tokens(self.tables, mlm_ids, out=emb_mlm)
         if c.sanity_checks:
-            assert int(flag.item()) == 0, "input images are outside [clip_min, clip_max]"
+            bits = int(flag.item())
+            assert bits == 0, "input images are outside [clip_min, clip_max]" if bits & 1 else "bad MLM label"
+        if hasattr(a, "set_mlm_rows"):
+            a.set_mlm_rows(None)
+            a.set_mlm_samples(None)
         res.substitutions = [text_update.substitution_lists(*r) for r in rounds]
-        res.adv_images, res.adv_text_ids = restore(cur[inv]), adv_ids[inv]
+        res.adv_images, res.adv_text_ids = restore(cur[inv]), adv_ids[inv][:, :text_len]
+        if any_dual:
+            res.adv_text_ids_mlm = mlm_ids[inv]
         res.loss_lists = [losses.tolist()]
         res.gradient_steps = sum(total)
         return res
+
+    @staticmethod
+    def _write_mlm_row(mlm_ids, mlm_mask, s, task):
+        """Row ``s`` of the batch's paraphrase ids / masks <- the task's current encoding (zero beyond its length)."""
+        n = len(task.text_ids_mlm)
+        mlm_ids[s].zero_()
+        mlm_mask[s].zero_()
+        mlm_ids[s, :n] = torch.tensor(task.text_ids_mlm, device=mlm_ids.device, dtype=mlm_ids.dtype)
+        mlm_mask[s, :n] = torch.tensor(task.text_mask_mlm, device=mlm_mask.device, dtype=mlm_mask.dtype)

@@ -67,13 +67,15 @@ def synthetic_images(qids, image_size, device):
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
               config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False,
               attack=None):
-    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps)`` on every rank.
+    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps, n_batches, mean_batch)`` on
+    every rank.
     ``attack``: a ready ``BatchedVQAttack`` (or an object with its ``attack_batch`` / ``attack_mixed`` / ``cfg``) instead
     of one built from ``adapters`` -- the multi-rank CPU tests inject a stand-in to exercise shard -> ledger -> gather.
 
     ``mixed=False``: samples are bucketed by (schedule, loss mode) and every batch is schedule-pure
-    (``BatchedVQAttack.attack_batch``).  ``mixed=True``: feature-loss samples are batched in index order whatever their
-    word counts (``attack_mixed``, prefix scheduling); dual-loss samples still go through their buckets."""
+    (``BatchedVQAttack.attack_batch``).  ``mixed=True``: ONE bucket -- samples are batched in index order whatever their
+    word counts and loss modes (``attack_mixed``: prefix scheduling, dual-loss samples alternate feature and MLM steps
+    inside the shared white-box pass)."""
     ids, masks, att = synthetic_questions(n_samples, text_len, seed=seed, joint=joint, max_words=max_words)
     tasks = synthetic_mlm_tasks(ids, dual_every, flavor, seed=seed, max_len=text_len if flavor == "vlmo" else None)
     dual = torch.tensor([t.old_alg == 0 for t in tasks])
@@ -83,9 +85,8 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
         attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
     ledger = SuccessLedger(world, rank, device)
     # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg;
-    # with mixed=True all feature-loss samples share ONE bucket (key -2) and are scheduled per sample inside the batch
-    buckets = bucket_by_schedule([(-2 if (mixed and not dual[i]) else int(att[i].sum()) * 2 + int(dual[i]))
-                                  for i in mine])
+    # with mixed=True all samples share ONE bucket (key -2) and are scheduled per sample inside the batch
+    buckets = bucket_by_schedule([(-2 if mixed else int(att[i].sum()) * 2 + int(dual[i])) for i in mine])
     writer = None
     if save_dir:
         from ..preprocess import AdvImageWriter
@@ -93,6 +94,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     adv_text = {}
     steps = 0
     done = 0
+    n_batches = 0
     t0 = time.perf_counter()
     for key, local in buckets.items():
         n_words, is_dual = key // 2, bool(key % 2)
@@ -102,7 +104,9 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             tid, tmask, tatt = ids[qids].to(device), masks[qids].to(device), att[qids].to(device)
             clean = black.vqa_answer(images, tid, tmask)
             if key == -2:
-                res = attack.attack_mixed(images, tid, tmask, tatt)
+                batch_tasks = [tasks[q] for q in qids]
+                res = attack.attack_mixed(images, tid, tmask, tatt,
+                                          tasks=batch_tasks if any(t.old_alg == 0 for t in batch_tasks) else None)
             elif is_dual:
                 res = attack.attack_batch(images, tid, tmask, tatt, dual=True, tasks=[tasks[q] for q in qids])
             else:
@@ -117,6 +121,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             if writer is not None:
                 writer.write(res.adv_images, qids)
             done += len(qids)
+            n_batches += 1
             if rank == 0 and log_every and done % log_every < len(qids):
                 bits = ledger.local_bits()
                 print("attack_accuracy", float(bits.float().mean().item()), "({} local samples)".format(done),
@@ -128,4 +133,5 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     dt = time.perf_counter() - t0
     asr = ledger.all_gather_rate()
     return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,
-                examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text)
+                examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text,
+                n_batches=n_batches, mean_batch=(len(mine) / n_batches if n_batches else 0.0))

@@ -240,6 +240,36 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
 
 
+def _mixed_loss_and_grad(model_fn, leaves, model_in, y, flavor, slot, mlm_labels=None, ws=None, flag=None):
+    """One white-box call for a batch whose samples stand at DIFFERENT steps of their own schedules (``attack_mixed``).
+
+    ``model_fn(model_in) -> (out, logits)``: ``out`` is the feature list of ``pgd_attack_vl`` with the rows of the samples
+    that take an MLM step this time weighted 0 (or None when every sample does), ``logits`` (n_mlm, W, V) the MLM head
+    at the live label positions of those samples (or None when there are none), ``mlm_labels`` their compact labels
+    (n_mlm, W) / (n_mlm, K, W).  Every sample's loss is one of the two terms of the reference's dual loop (feature loss
+    A fast_gradient_method.py:120-127 / V :106-114, or MLM cross entropy A :128-142 / V :115-126, normalised per sample);
+    samples do not interact in a frozen eval-mode network, so one backward of the SUM leaves each sample's own gradient
+    in its slice of ``leaf.grad``."""
+    with torch.enable_grad():
+        out, logits = model_fn(model_in)
+        ce = None
+        if logits is not None:
+            sets = _label_sets(mlm_labels)
+
+            def ce(accumulate=True):
+                return _ce_backward(logits, sets, slot, leaves, 1.0, accumulate=accumulate, flag=flag, ws=ws,
+                                    per_sample=True)
+        if out is not None:
+            _feature_loss_backward(_feature_pairs(out, y, flavor, vl=True), slot, leaves, 1.0, ws=ws, extra=ce)
+        elif ce is not None:
+            t, g = ce(accumulate=False)
+            if not t:
+                raise RuntimeError("model_fn's logits do not depend on the attacked input")
+            torch.autograd.backward(t, g, inputs=leaves)
+        else:
+            raise RuntimeError("mixed model_fn returned neither features nor logits")
+
+
 # ----------------------------------------------------------------------------------------- image updates
 def _fgm_update(x, grad, eps, norm, clip_min, clip_max, flag=None, out=None):
     if norm == np.inf:

@@ -11,8 +11,8 @@
 // exp is the hardware v_exp_f32 path (__expf, ~2 ulp); the tests state 1e-4 relative against torch.
 // A label that is neither ignore_index nor in [0, V) poisons the loss with NaN and ORs VQA_FLAG_BAD_LABEL into *flag
 // (torch device-asserts on such a label; it is never silently dropped).
-// Algorithmic bytes: 4*V read + 4*V written per row (8*V), against ~6 full passes per label set for log_softmax +
-// nll_loss + their autograd backward.
+// Algorithmic bytes: 4*V read + 4*V written per live row (8*V), 4*V written per dead row (all labels ignore_index: zero
+// gradient, logits untouched), against ~6 full passes per label set for log_softmax + nll_loss + their autograd backward.
 #include "common.hpp"
 
 extern "C" int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
@@ -97,6 +97,18 @@ __device__ __forceinline__ RowLabels<MAXK> read_labels(const int64_t* __restrict
   return L;
 }
 
+// A row none of whose K labels is a target (all ignore_index) has loss 0 and an identically zero gradient whatever its
+// logits are.  In the reference's workload that is every position except the [MASK]-ed answer pieces
+// (adv_attack.py:433-558: labels are -100 elsewhere), i.e. >= 90 % of the B x L rows of a dense (B, L, V) logits tensor:
+// such a row's logits are never loaded and no exponential is evaluated -- it costs its zero gradient store only
+// (4 V bytes instead of 8 V).  The labels of a row are the same for the whole workgroup: the branch is scalar.
+__device__ __forceinline__ bool row_is_dead(const int64_t* __restrict__ labels, int K, long rows, long r,
+                                            long ignore_index) {
+  bool live = false;
+  for (int k = 0; k < K; ++k) live |= (labels[static_cast<long>(k) * rows + r] != ignore_index);
+  return !live;
+}
+
 struct CeFold {          // in-kernel fold of row_loss into the scalar loss (loss_out == NULL: row losses only)
   unsigned* counter;
   float* loss_out;
@@ -145,6 +157,14 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
                                                          float gscale, int* __restrict__ flag) {
   __shared__ float lds_m[kWaves], lds_s[kWaves];
   const long r = blockIdx.x;
+  if (row_is_dead(labels, K, rows, r, ignore_index)) {       // nothing to learn from this row: zero loss, zero gradient
+    if (threadIdx.x == 0) row_loss[r] = 0.0f;
+    if (GRAD) {
+      float* g = grad + r * static_cast<long>(V);
+      for (int j = threadIdx.x; j < V; j += kBlock) g[j] = 0.0f;
+    }
+    return;
+  }
   const float* x = logits + r * row_stride;
   const bool vec = ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   // ---- sweep 1: online softmax statistics
@@ -256,6 +276,23 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
   __shared__ float lds[kWavesT];
   const long r = blockIdx.x;
   const RowGeom cur = row_geom(logits, r, V);
+  if (row_is_dead(labels, K, rows, r, ignore_index)) {       // workgroup-uniform: no logits load, no exp, zeros out
+    if (threadIdx.x == 0) __hip_atomic_store(row_loss + r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (GRAD) {
+      float* g = grad + r * static_cast<long>(V);
+      const int edge = edge_index(cur, V);
+      if (edge >= 0) g[edge] = 0.0f;
+      f32x4* g4 = reinterpret_cast<f32x4*>(g + cur.head);
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < kQuads; ++i) {
+        const int j = i * THREADS + threadIdx.x;
+        if (j < cur.nquad) __builtin_nontemporal_store(zero, g4 + j);
+      }
+    }
+    fold_row_losses<THREADS>(fold, row_loss, rows);
+    return;
+  }
   f32x4 v[kQuads];
 #pragma unroll
   for (int i = 0; i < kQuads; ++i) {

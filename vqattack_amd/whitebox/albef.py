@@ -279,9 +279,12 @@ class FrozenAlbef(nn.Module):
         _, txt_feats = self.text_encoder(text_embeds, text_masks, image_states)
         return img_feats, txt_feats
 
-    def get_mlm_logits(self, image, text_ids, text_masks):
+    def get_mlm_logits(self, image, text_ids, text_masks, rows=None):
+        """``rows`` (B, W) int64: evaluate the MLM head at these text positions only (``mlm_task.live_label_rows``)."""
         image_states, _ = self.visual_encoder(image)
         states, _ = self.text_encoder(self.text_embeddings(self.mask_tokens(text_ids)), text_masks, image_states)
+        if rows is not None:
+            states = torch.gather(states, 1, rows.unsqueeze(-1).expand(-1, -1, states.shape[-1]))
         return self.mlm_head(states)
 
     # ---- black-box VQA scorer: batched rank_answer (model_vqa.py:149-203) ----------------------------------------
@@ -346,6 +349,24 @@ class AlbefAttackAdapters:
     def __init__(self, model):
         self.model = model
         self.batch = {}
+        self._mlm_rows = None
+        self._mlm_samples = None
+
+    def set_mlm_samples(self, index):
+        """Batch indices (int64 device tensor) of the samples taking an MLM step in the next ``pgd_attack_mixed`` calls."""
+        self._mlm_samples = None if index is None or index.numel() == 0 else index
+
+    def save_text(self):
+        return (dict(self.batch), self._tlen, self._weight)
+
+    def load_text(self, state):
+        batch, self._tlen, self._weight = state
+        self.batch = dict(batch)
+
+    def set_mlm_rows(self, rows):
+        """Live-rows form of ``pgd_mlm_attack`` (see ``VlmoAttackAdapters.set_mlm_rows``): logits (B, W, V) at the text
+        positions ``rows`` (B, W) only; ``None`` = the reference's dense (B, L, V) closure (adv_attack.py:130-140)."""
+        self._mlm_rows = None if rows is None else rows.contiguous()
 
     def set_text(self, text_ids, text_masks, text_ids_mlm=None, text_mask_mlm=None, text_len=None):
         self._tlen = text_ids.shape[1]          # no trimming here: the caller passes the text at its own length
@@ -383,5 +404,31 @@ class AlbefAttackAdapters:
         img, txt = self.model.gen_feats_from_embeds(xs[0], xs[1], self.batch["text_ids"], self.batch["text_masks"])
         return self._pack(img, txt)
 
+    def pgd_attack_mixed(self, xs):
+        """One pass for a batch whose samples stand at different steps of their schedules (``attack_mixed``): per sample
+        the current text batch / ``xs[1]`` hold the question (feature step, ``pgd_attack[_vl]``, adv_attack.py:119-126 /
+        :208-214) or the [MASK]-ed paraphrase (MLM step, ``pgd_mlm_attack`` :130-140: the MLM head on the fused text
+        states).  Returns ``(features or None, logits (n_mlm, W, V) at the live label rows or None)``; the feature rows of
+        the MLM-step samples are weighted 0.  Text embeddings come from ``xs[1]`` as in ``Gen_feats_from_embeds``: the
+        per-forward random token masking does not act on them (``mlm_probability`` is a no-op on this path)."""
+        m = self.model
+        image_states, img_feats = m.visual_encoder(xs[0])
+        states, txt_feats = m.text_encoder(xs[1], self.batch["text_masks"], image_states)
+        sel = self._mlm_samples
+        if sel is None:
+            return self._pack(img_feats, txt_feats), None
+        if self._mlm_rows is None:
+            raise RuntimeError("pgd_attack_mixed with MLM-step samples needs set_mlm_rows() first")
+        idx = self._mlm_rows[sel].unsqueeze(-1).expand(-1, -1, states.shape[-1])
+        logits = m.mlm_head(torch.gather(states[sel], 1, idx))
+        if sel.numel() == xs[0].shape[0]:
+            return None, logits
+        wt = self._weight.clone()
+        wt[sel] = 0
+        wi = torch.ones(img_feats[0].shape[:2], dtype=torch.uint8, device=wt.device)
+        wi[sel] = 0
+        return [LayerFeatures(txt_feats, wt), LayerFeatures(img_feats, wi)], logits
+
     def pgd_mlm_attack(self, x):
-        return [self.model.get_mlm_logits(x, self.batch["text_ids_mlm"], self.batch["text_mask_mlm"])]
+        return [self.model.get_mlm_logits(x, self.batch["text_ids_mlm"], self.batch["text_mask_mlm"],
+                                          rows=self._mlm_rows)]

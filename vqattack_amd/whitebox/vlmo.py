@@ -326,6 +326,8 @@ class VlmoAttackAdapters:
         self.batch = {}
         self.trim_padding = trim_padding
         self._tlen = model.cfg.max_text_len
+        self._mlm_rows = None
+        self._mlm_samples = None
 
     def _text_len(self, masks):
         full = self.model.cfg.max_text_len
@@ -347,6 +349,30 @@ class VlmoAttackAdapters:
         self._weight = None
         self._bias = self.model.attention_bias(self.batch["text_masks"])
         self._bias_mlm = self._bias if text_mask_mlm is None else self.model.attention_bias(self.batch["text_mask_mlm"])
+
+    def set_mlm_rows(self, rows):
+        """Live-rows form of the MLM closure: ``rows`` int64 (B, W) = the text positions whose MLM labels are targets
+        (``mlm_task.live_label_rows``); ``pgd_mlm_attack`` then returns logits (B, W, V) for those positions only, to be
+        scored against the equally compacted labels.  ``None`` restores the dense (B, max_text_len, V) contract of the
+        reference's closure (vlmo_module.py:1448-1529).  In the reference's workload >= 90 % of the positions carry
+        ``ignore_index``: the dense form runs the 768 x 30522 head on them, writes their logits, and the loss writes
+        their all-zero gradient rows (625 MB each way per iteration at batch 64)."""
+        self._mlm_rows = None if rows is None else rows.contiguous()
+
+    def set_mlm_samples(self, index):
+        """int64 device tensor with the batch indices of the samples that take an MLM step in the following
+        ``pgd_attack_mixed`` calls (None / empty: nobody does)."""
+        self._mlm_samples = None if index is None or index.numel() == 0 else index
+
+    def save_text(self):
+        """Opaque snapshot of the current text batch (ids, masks, trimmed length, row weights, attention masks): a
+        driver that alternates between two text batches restores them with ``load_text`` instead of rebuilding the
+        per-layer attention masks every step."""
+        return (dict(self.batch), self._tlen, self._weight, self._bias, self._bias_mlm)
+
+    def load_text(self, state):
+        batch, self._tlen, self._weight, self._bias, self._bias_mlm = state
+        self.batch = dict(batch)
 
     def text_embeddings(self, ids):
         return self.model.text_embeddings(ids)
@@ -392,11 +418,36 @@ class VlmoAttackAdapters:
         feats, states = self.model.encode(xs[0], xs[1][:, :self._tlen], self.batch["text_masks"], self._bias)
         return self._pack(feats, states)
 
+    def pgd_attack_mixed(self, xs):
+        """One encoder pass for a batch whose samples stand at different steps of their schedules (``attack_mixed``):
+        the current text batch holds, per sample, the question (feature step: ``pgd_attack`` / ``pgd_attack_vl``,
+        vlmo_module.py:1387-1446 / :1328-1385) or the [MASK]-ed paraphrase (MLM step: ``pgd_mlm_attack``, :1448-1529).
+        Returns ``(features, logits)``: the feature list with the rows of the MLM-step samples weighted 0 (None when every
+        sample is one), and the MLM logits (n_mlm, W, V) of those samples at their live label rows (None when there are
+        none).  ``xs[1]`` holds the text embeddings of all positions, per sample those of the text it is run with."""
+        m = self.model
+        feats, states = m.encode(xs[0], xs[1][:, :self._tlen], self.batch["text_masks"], self._bias)
+        sel = self._mlm_samples
+        if sel is None:
+            return self._pack(feats, states), None
+        if self._mlm_rows is None:
+            raise RuntimeError("pgd_attack_mixed with MLM-step samples needs set_mlm_rows() first")
+        idx = self._mlm_rows[sel].unsqueeze(-1).expand(-1, -1, states.shape[-1])
+        logits = m.mlm_score(torch.gather(states[sel], 1, idx))
+        if sel.numel() == xs[0].shape[0]:
+            return None, logits
+        w = self.row_weight().clone()
+        w[sel] = 0
+        return [m.pooled(states), None, LayerFeatures(feats, w)], logits
+
     def pgd_mlm_attack(self, x):
         m = self.model
         feats, states = m.encode(x, m.text_embeddings(self.batch["text_ids_mlm"]), self.batch["text_mask_mlm"],
                                  self._bias_mlm)
+        if self._mlm_rows is not None:          # live rows only: no logits for positions whose labels are ignore_index
+            idx = self._mlm_rows.unsqueeze(-1).expand(-1, -1, states.shape[-1])
+            return [m.mlm_score(torch.gather(states, 1, idx)), None, LayerFeatures(feats, self.row_weight())]
         logits = m.mlm_score(states[:, :self._tlen])
-        if self._tlen < m.cfg.max_text_len:     # labels cover max_text_len positions; trimmed ones are ignore_index
-            logits = torch.nn.functional.pad(logits, (0, 0, 0, m.cfg.max_text_len - self._tlen))
+        if self._tlen < m.cfg.max_text_len:     # dense contract: labels cover max_text_len positions (trimmed ones must
+            logits = F.pad(logits, (0, 0, 0, m.cfg.max_text_len - self._tlen))   # be ignore_index; the runner checks)
         return [logits, None, LayerFeatures(feats, self.row_weight())]
