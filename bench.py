@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--joint", type=int, default=0, metavar="WORDS",
                     help="joint image+text attack with this many substitutable words per question (configs[4]); "
                          "0 = image-only PGD (configs[1], the default metric)")
+    ap.add_argument("--dual", action="store_true",
+                    help="dual-loss attack (the reference's old_alg == 0 samples): every PGD iteration is a feature step + "
+                         "an MLM step on the [MASK]-ed paraphrase; --pgd-steps counts white-box gradient steps")
+    ap.add_argument("--dense-mlm", action="store_true",
+                    help="with --dual: MLM head and cross entropy over all B x L positions (the reference's dense "
+                         "closure) instead of the live label rows only -- the 'before' of profiles/r03")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=40,
                     help="PGD steps of the CPU sample (default: one full 40-step example, ~10-15 s on 16 cores)")
@@ -266,6 +272,8 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
 def baseline_config(args):
     """Which entry of BASELINE.json's ``configs`` the run is (the default run is configs[1])."""
     full = args.pgd_steps == 40 and args.image_size == 384
+    if args.dual:
+        return "not a BASELINE config: dual-loss variant"
     if full and args.model == "vlmo_base" and not args.joint and args.batch == 64:
         return "BASELINE configs[1]" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "BASELINE configs[3] shape"
     if full and args.model == "albef_base" and not args.joint and args.batch == 256:
@@ -350,7 +358,8 @@ def main():
     cfg = make_config(args)
     flavor, white, black, adapters, text_len = build_models(args, cfg, device)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
-                             AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False))
+                             AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False,
+                                          live_mlm_rows=not args.dense_mlm))
     ledger = SuccessLedger(world, rank, coll_device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -361,9 +370,17 @@ def main():
     if args.joint:
         words[:, 1:1 + min(args.joint, text_len - 2)] = True     # configs[4]: joint image + text attack
     clean_answers = black.vqa_answer(images, ids, masks)
+    tasks = None
+    if args.dual:           # every sample's victim answer occurs in its paraphrase -> old_alg == 0 (adv_attack.py:455-469)
+        from vqattack_amd.attack.sweep import synthetic_mlm_tasks
+        tasks = synthetic_mlm_tasks(ids.cpu(), 1, flavor, seed=rank, max_len=text_len if flavor == "vlmo" else None)
+        assert all(t.old_alg == 0 for t in tasks)
 
     def one_step():
-        res = attack.attack_batch(images, ids, masks, words)
+        if tasks is not None:
+            res = attack.attack_batch(images, ids, masks, words, dual=True, tasks=tasks)
+        else:
+            res = attack.attack_batch(images, ids, masks, words)
         adv_answers = black.vqa_answer(res.adv_images, res.adv_text_ids, masks)
         ledger.record(adv_answers != clean_answers)
         return res
@@ -406,8 +423,11 @@ def main():
             "config": {"workload": "{} VQAttack {} ({}): batch {} per GPU, {} PGD steps, {}x{} images, questions of "
                                    "{} real tokens ([CLS] + {} words + [SEP]) padded to {}{}, eps 0.125 step 0.01 L-inf "
                                    "clip [-1,1], random start, black-box scoring + ASR gather".format(
-                                       args.model, "joint image+text attack ({} words)".format(args.joint)
-                                       if args.joint else "image PGD", baseline_config(args), args.batch,
+                                       args.model, ("joint image+text attack ({} words)".format(args.joint)
+                                                    if args.joint else "image PGD") +
+                                       ((", dual loss (feature + MLM step per iteration, MLM head on {})".format(
+                                           "all positions" if args.dense_mlm else "the live label rows"))
+                                        if args.dual else ""), baseline_config(args), args.batch,
                                        args.pgd_steps, cfg.image_size, cfg.image_size, n_body + 2, n_body, text_len,
                                        " (the all-padding columns are not run through the encoder)"
                                        if flavor == "vlmo" else ""),
@@ -415,6 +435,9 @@ def main():
                        "text_len": text_len, "real_tokens": n_body + 2, "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
+            "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
+                            "tensor_device": str(coll_device), "calls": ledger.collectives}
+                           if use_dist else None),
             "roofline": roof,
             "roofline_loss": roof_loss,
         }

@@ -11,6 +11,8 @@ import yaml
 
 from _common import finish, init_distributed
 
+import torch.distributed as dist  # noqa: E402  (after _common: it sets the HSA IPC mode before torch loads)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -33,7 +35,7 @@ def main():
     res = run_sweep("albef", white, black, AlbefAttackAdapters(white), args.n_samples or cfg["n_samples"],
                     cfg["batch_size_test"], mcfg.image_size, min(cfg["text_len"], 8 if args.tiny else 512), device,
                     rank, world, joint=not args.image_only, save_dir=out_dir, seed=args.seed,
-                    max_words=4 if args.tiny else 12)
+                    max_words=4 if args.tiny else 12, force_collective=dist.is_initialized())
     finish(rank, world, res, os.path.join(args.output_dir, "adv_txt.json") if args.output_dir else None)
 
 

@@ -23,7 +23,9 @@ def init_distributed():
     if not torch.cuda.is_available():
         raise SystemExit("the attack path runs on MI355X GPUs only (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
+    # any torchrun launch initialises RCCL, also a 1-rank one: the success bits then go through the same device-tensor
+    # all-gather as on 8 GPUs (run_sweep(force_collective=dist.is_initialized()))
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     return rank, world, torch.device("cuda", local)
 
@@ -34,6 +36,9 @@ def finish(rank, world, result, out_json=None):
         if out_json:
             with open(out_json, "w") as f:
                 json.dump(result["adv_text"], f)
-    if world > 1:
+    if dist.is_initialized():
+        if rank == 0:
+            print("dist_backend", dist.get_backend(), "world", dist.get_world_size(), "collectives",
+                  result.get("collectives"), flush=True)
         dist.barrier()
         dist.destroy_process_group()

@@ -10,6 +10,8 @@ import sys
 
 from _common import finish, init_distributed
 
+import torch.distributed as dist  # noqa: E402  (after _common: it sets the HSA IPC mode before torch loads)
+
 NAMED = {
     "task_finetune_vqa_base_image384": dict(arch="vlmo_base", image_size=384),
     "task_finetune_vqa_base_image480": dict(arch="vlmo_base", image_size=480),
@@ -53,7 +55,8 @@ def main():
     res = run_sweep("vlmo", white, black, vlmo.VlmoAttackAdapters(white), cfg["n_samples"], cfg["per_gpu_batchsize"],
                     mcfg.image_size, mcfg.max_text_len, device, rank, world, joint=not cfg["image_only"],
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],
-                    max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"])
+                    max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"],
+                    force_collective=dist.is_initialized())
     finish(rank, world, res)
 
 

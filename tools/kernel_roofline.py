@@ -150,6 +150,15 @@ def cos_section(b):
     report("vqa_neg_cos_rows_multi ({} layers, row weights)".format(n_layers), 12 * live * 768 * n_layers,
            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
                   reps=10))
+    # A/B: targets normalised once per attack -> the |b|^2 chain leaves the kernel (vqa_set_option(9, 1))
+    tn = [t / t.norm(dim=-1, keepdim=True).clamp_min(1e-6) for t in tl]
+    for bn, tgt in ((1, tn), (0, tl), (1, tn), (0, tl)):
+        assert _hip.lib().vqa_set_option(9, bn) == 0
+        report("vqa_neg_cos_rows_multi ({} layers, D=768) [targets {}]".format(
+            n_layers, "pre-normalised, no |b|^2 chain" if bn else "raw (shipped)"), 12 * rows * 768 * n_layers,
+            timeit(lambda: ops.neg_cos_rows_multi(al, tgt, slot, accumulate=False, ws=ws), reps=10), "A/B")
+    assert _hip.lib().vqa_set_option(9, 0) == 0
+    del tn
     for nt in (0, 5, 6, 7, 4):
         assert _hip.lib().vqa_set_option(8, nt) == 0
         report("vqa_neg_cos_rows_multi ({} layers, D=768) [nt mask {}: a loads {}, grad stores {}, b loads {}]".format(
@@ -194,6 +203,27 @@ def ce_section(b):
            timeit(lambda: ops.mlm_cross_entropy(logits, labels3, slot, accumulate=False, ws=ws)))
     report("vqa_ce_rows (loss only, K=1)", 4 * rows * 30522,
            timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, want_grad=False, ws=ws)))
+
+    # the reference's workload: labels are ignore_index except at the [MASK]-ed answer pieces (adv_attack.py:433-558).
+    # Dense (B x 40 rows) with dead rows skipped in the kernel: a dead row costs its zero gradient store, 4 V bytes.
+    for dead_frac, live_per_sample in ((0.9, 4), (0.975, 1)):
+        lab = torch.full((1, rows), -100, dtype=torch.long, device="cuda")
+        for s in range(b):
+            lab[0, s * 40 + 1:s * 40 + 1 + live_per_sample] = torch.randint(0, 30522, (live_per_sample,), device="cuda")
+        live = int((lab != -100).sum())
+        report("vqa_ce_rows (loss+grad, K=1, dense {} x 30522, {:.1%} dead rows skipped in-kernel)".format(
+            rows, 1 - live / rows), (8 * live + 4 * (rows - live)) * 30522,
+            timeit(lambda: ops.mlm_cross_entropy(logits, lab, slot, accumulate=False, ws=ws, rows_per_sample=40)),
+            "8 V bytes per live row + 4 V per dead row (zero gradient)")
+        # live-rows form: what the bundled adapters hand over -- only the live rows exist at all
+        small = logits[:b * live_per_sample].contiguous().reshape(b, live_per_sample, 30522)
+        lab_s = torch.randint(0, 30522, (1, b * live_per_sample), device="cuda")
+        ws2 = ops.Workspace()
+        report("vqa_ce_rows (loss+grad, K=1, live-rows form: {} x 30522)".format(b * live_per_sample),
+               8 * b * live_per_sample * 30522,
+               timeit(lambda: ops.mlm_cross_entropy(small, lab_s, slot, accumulate=False, ws=ws2,
+                                                    rows_per_sample=live_per_sample)),
+               "latency-bound: {} workgroups on 256 CUs".format(b * live_per_sample))
 
     def torch_ce():
         lg = logits.detach().requires_grad_(True)

@@ -3,7 +3,7 @@
 # per-kernel summary.  usage: tools/pmc_run.sh <out_dir> [phases...]
 set -e -o pipefail
 out=$1; shift
-phases=${@:-step64 step256 cos13 cos25 ce sumsq}
+phases=${@:-step64 step256 cos13 cos25 ce ce_dead attn sumsq}
 mkdir -p "$out"
 export TMPDIR=/tmp
 for ph in $phases; do

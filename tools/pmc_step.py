@@ -5,7 +5,9 @@ SEPARATE runs, kernel-trace only -- see /opt/skills/guides/MI355X_MICROARCH.md, 
 
 phases: step64 | step256 (fused L-inf step, batch 64 / 256), cos13 (vqa_neg_cos_rows_multi: 13 VLMO-base maps of batch 64
 in one launch, 10 real text tokens of 40 like the bench workload), cos25 (25 VLMO-large maps, D = 1024), ce (MLM cross
-entropy, 2560 x 30522), sumsq (per-sample sum of squares, batch 64).  One phase per run keeps the per-launch counters of
+entropy, 2560 x 30522), ce_dead (the same launch with the reference's label pattern: 1 live row of 40), attn (the white
+box's attention forward + backward at the bench shape, saved-scores / dS^T-workspace form), sumsq (per-sample sum of
+squares, batch 64).  One phase per run keeps the per-launch counters of
 different shapes apart (the B=64 and B=256 step launches share a grid)."""
 import os
 import sys
@@ -43,6 +45,34 @@ elif phase == "ce":
     labels = torch.randint(0, 30522, (1, 64 * 40), device="cuda")
     for _ in range(3):
         ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, ws=ws)
+elif phase == "ce_dead":
+    # the reference's label pattern: 1 live position of 40 per sample (97.5 % dead rows): a dead row's logits are never
+    # fetched, its zero gradient row is written -> expected traffic ~ 8 V x 64 + 4 V x 2496 bytes
+    ws = ops.Workspace()
+    logits = torch.randn(64 * 40, 30522, device="cuda")
+    labels = torch.full((1, 64 * 40), -100, dtype=torch.long, device="cuda")
+    labels[0, 4::40] = torch.randint(0, 30522, (64,), device="cuda")
+    for _ in range(3):
+        ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, ws=ws, rows_per_sample=40)
+elif phase == "attn":
+    # the white box's attention at the bench shape, in the form the attack's autograd path runs: a forward that saves
+    # its scores, a backward that starts from them and keeps dS^T in the transient workspace (4 products)
+    from vqattack_amd import attention
+    b, h, sq = 64, 12, 587
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    qkv = torch.randn(b, sq, 3, h, 64, device="cuda", generator=gen)
+    store = torch.zeros(1, h, sq, (sq + 31) // 32 * 32, device="cuda")
+    store[..., :sq] = torch.randn(1, h, sq, sq, device="cuda", generator=gen) * 0.02
+    bias = store[..., :sq].expand(b, -1, -1, -1)
+    bstr = (bias.stride(0), bias.stride(1), bias.stride(2))
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    go = torch.randn(b, sq, h, 64, device="cuda", generator=gen)
+    dqkv = torch.empty_like(qkv)
+    for _ in range(3):
+        o, lse, scores = attention._forward(q, k, v, bias, bstr, 0.125, save_scores=True)
+        assert scores is not None
+        attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], 0.125,
+                            scores=scores)
 elif phase == "sumsq":
     g = torch.randn(64, 3, 384, 384, device="cuda")
     for _ in range(3):

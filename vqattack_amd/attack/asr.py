@@ -21,6 +21,7 @@ class SuccessLedger:
     def __init__(self, world=1, rank=0, device="cpu", force_collective=False):
         self.world, self.rank, self.device = world, rank, torch.device(device)
         self.force_collective = force_collective     # run the all-gather even for world == 1 (1-rank torchrun)
+        self.collectives = 0                         # all_gather / all_reduce calls issued so far (evidence for tests)
         self.reset()
 
     def reset(self):
@@ -51,6 +52,7 @@ class SuccessLedger:
         n = torch.tensor([bits.numel(), has_ids], device=self.device, dtype=torch.int64)
         meta = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(meta, n)
+        self.collectives += 1
         counts = [int(m[0].item()) for m in meta]
         with_ids = all(int(m[1].item()) == 1 for m in meta)
         cap = max(counts) if counts else 0
@@ -58,6 +60,7 @@ class SuccessLedger:
         pad[:bits.numel()] = bits
         parts = [torch.zeros_like(pad) for _ in range(self.world)]
         dist.all_gather(parts, pad)
+        self.collectives += 1
         all_bits = torch.cat([p[:c] for p, c in zip(parts, counts)])
         all_ids = None
         if with_ids:
@@ -66,6 +69,7 @@ class SuccessLedger:
                 ipad[:ids.numel()] = ids
             iparts = [torch.zeros_like(ipad) for _ in range(self.world)]
             dist.all_gather(iparts, ipad)
+            self.collectives += 1
             all_ids = torch.cat([p[:c] for p, c in zip(iparts, counts)])
         return all_bits, all_ids
 
@@ -77,6 +81,7 @@ class SuccessLedger:
         pair = torch.tensor([float(bits.sum().item()), float(bits.numel())], device=self.device, dtype=torch.float64)
         if self.world > 1 or self.force_collective:
             dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+            self.collectives += 1
         return float(pair[0] / pair[1]) if float(pair[1]) > 0 else None
 
     def all_gather_rate(self):

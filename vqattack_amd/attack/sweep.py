@@ -66,7 +66,7 @@ def synthetic_images(qids, image_size, device):
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
               config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False,
-              attack=None):
+              attack=None, force_collective=False):
     """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps, n_batches, mean_batch)`` on
     every rank.
     ``attack``: a ready ``BatchedVQAttack`` (or an object with its ``attack_batch`` / ``attack_mixed`` / ``cfg``) instead
@@ -83,7 +83,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     device = torch.device(device)
     if attack is None:
         attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
-    ledger = SuccessLedger(world, rank, device)
+    ledger = SuccessLedger(world, rank, device, force_collective=force_collective)   # True: a 1-rank torchrun launch
     # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg;
     # with mixed=True all samples share ONE bucket (key -2) and are scheduled per sample inside the batch
     buckets = bucket_by_schedule([(-2 if mixed else int(att[i].sum()) * 2 + int(dual[i])) for i in mine])
@@ -134,4 +134,5 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     asr = ledger.all_gather_rate()
     return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,
                 examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text,
-                n_batches=n_batches, mean_batch=(len(mine) / n_batches if n_batches else 0.0))
+                n_batches=n_batches, mean_batch=(len(mine) / n_batches if n_batches else 0.0),
+                collectives=ledger.collectives)

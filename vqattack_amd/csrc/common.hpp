@@ -9,7 +9,7 @@ namespace vqa {
 
 constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup, one per SIMD
-constexpr int kMaxBlocks = 256 * 8;  // default grid cap (256 CUs x 8 workgroups); launchers that care query cu_count()
+constexpr int kBlocksPerCu = 8;    // default grid cap of a grid-stride launch: 8 workgroups per compute unit (grid_cap())
 
 // torch.sign: (g > 0) - (g < 0); sign(+-0) = 0 and sign(NaN) = 0.
 __device__ __forceinline__ float sign_torch(float g) {
@@ -95,13 +95,6 @@ __device__ __forceinline__ void arrive_reset(unsigned* counters) {      // by th
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
-inline int blocks_for(size_t work_items, int per_block, int cap = kMaxBlocks) {
-  size_t b = (work_items + per_block - 1) / per_block;
-  if (b < 1) b = 1;
-  if (b > static_cast<size_t>(cap)) b = cap;
-  return static_cast<int>(b);
-}
-
 // Compute units of the current device, queried once per device (MI355X: 256).
 inline int cu_count() {
   static int cached[64] = {0};
@@ -113,6 +106,16 @@ inline int cu_count() {
     cached[dev] = n;
   }
   return cached[dev];
+}
+
+inline int grid_cap() { return cu_count() * kBlocksPerCu; }
+
+inline int blocks_for(size_t work_items, int per_block, int cap = 0) {      // cap <= 0: grid_cap()
+  if (cap <= 0) cap = grid_cap();
+  size_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > static_cast<size_t>(cap)) b = cap;
+  return static_cast<int>(b);
 }
 
 // Workgroups of `kernel` that are resident at once on the whole device (occupancy x CUs): the grid of a persistent /

@@ -19,7 +19,7 @@ constexpr int kMaxChunks = 512;          // partials per sample (stage 2 folds t
 static int chunks_for(int batch, size_t n_per) {
   size_t per_block = static_cast<size_t>(kBlock) * kRedU * 4;   // elements one workgroup covers per sweep
   size_t c = (n_per + per_block - 1) / per_block;
-  size_t cap = static_cast<size_t>(kMaxBlocks) * 2 / (batch > 0 ? batch : 1);
+  size_t cap = static_cast<size_t>(grid_cap()) * 2 / (batch > 0 ? batch : 1);
   if (cap < 1) cap = 1;
   if (cap > kMaxChunks) cap = kMaxChunks;
   if (c > cap) c = cap;
@@ -278,7 +278,7 @@ static int launch_per_sample(const float* s0, const float* s1, const float* stat
   if (batch == 0 || n_per == 0) return VQA_OK;
   const bool vec = (n_per % 4 == 0) && aligned16(s0) && aligned16(out) && (!TWO || aligned16(s1));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int gx = blocks_for(vec ? n_per / 4 : n_per, vec ? kBlock * kRedU : kBlock, kMaxBlocks / (batch < 8 ? batch : 8));
+  int gx = blocks_for(vec ? n_per / 4 : n_per, vec ? kBlock * kRedU : kBlock, grid_cap() / (batch < 8 ? batch : 8));
   dim3 grid(gx, batch);
   if (vec)
     per_sample_kernel<KIND, true, TWO><<<grid, kBlock, 0, st>>>(s0, s1, stat, stat2, out, n_per, p, flag);

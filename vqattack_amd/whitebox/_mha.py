@@ -5,7 +5,8 @@ transpose copy.  On the GPU every fp32 attention of the white boxes runs on the 
 ``csrc/attn.hip`` (``vqattack_amd.attention``); a missing HIP library is an error, not a fallback.  The kernels are built
 for the head size of every BASELINE configuration, d = 64 (VLMo-base / -large, ALBEF); the test-sized models have
 narrower heads, which are zero-padded to 64 here (zero dimensions add nothing to q k^T and produce zero output
-columns; the softmax scale stays d ** -0.5 of the true width).  Host tensors -- the white boxes also run on the CPU, as
+columns; the softmax scale stays d ** -0.5 of the true width); wider heads or another dtype on the GPU raise
+``HipExtensionError``.  Host tensors -- the white boxes also run on the CPU, as
 the frozen model behind the oracle in ``tests/`` -- go through PyTorch's ``scaled_dot_product_attention``.
 """
 import torch
@@ -15,7 +16,16 @@ from .. import attention as _attn
 
 
 def _on_gpu(t):
-    return t.is_cuda and t.dtype == torch.float32 and t.shape[-1] <= _attn.HEAD_DIM
+    """True: the HIP kernels run.  A GPU tensor they cannot take is an error, never a silent library fallback."""
+    if not t.is_cuda:
+        return False
+    if t.dtype != torch.float32:
+        raise _attn._hip.HipExtensionError("the white boxes' attention runs in fp32 on csrc/attn.hip, got {}".format(t.dtype))
+    if t.shape[-1] > _attn.HEAD_DIM:
+        raise _attn._hip.HipExtensionError(
+            "csrc/attn.hip is built for heads of at most {} dimensions (every BASELINE configuration has 64), got {}; "
+            "there is no library fallback on the GPU".format(_attn.HEAD_DIM, t.shape[-1]))
+    return True
 
 
 def _pad(t):
