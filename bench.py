@@ -99,8 +99,33 @@ def build_models(args, cfg, device):
 
 
 # HBM traffic per launch is NOT measured by this script (PMC counters need their own rocprofv3 passes): the tracked
-# summary below holds FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch for the kernels timed here.
-PMC_SUMMARY = "profiles/r02/pmc_hot_kernels_summary.txt"
+# summary below holds FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch for the kernels timed here
+# (tools/pmc_run.sh on the shipped build).  When a run's launch has the shape of a recorded phase, the recorded figure is
+# copied into the line as `traffic` with `traffic_kind: "recorded"`.
+PMC_SUMMARY = "profiles/r03/pmc_hot_kernels_summary.txt"
+
+
+def recorded_traffic(phase, kernel):
+    """HBM bytes per launch of `kernel` (substring of the kernel name) in phase `phase` of the tracked PMC summary."""
+    try:
+        lines = open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()
+    except OSError:
+        return None
+    current = None
+    for ln in lines:
+        if ln.startswith("== phase"):
+            current = ln.split()[-1]
+        elif current == phase and kernel in ln and "HBM traffic" in ln:
+            return int(round(float(ln.split("HBM traffic")[1].split("MB")[0]) * 1e6))
+    return None
+
+
+def traffic_fields(phase, kernel, shape_note):
+    t = recorded_traffic(phase, kernel) if phase else None
+    if t is None:
+        return dict(traffic=None, traffic_source=PMC_SUMMARY)
+    return dict(traffic=t, traffic_kind="recorded", traffic_source="{} (phase {}: {})".format(PMC_SUMMARY, phase,
+                                                                                            shape_note))
 
 
 class KernelTimer:
@@ -154,7 +179,8 @@ class KernelTimer:
         ms = [a.elapsed_time(b) for a, b in events]
         return (sum(ms) / len(ms), min(ms), len(ms)) if ms else (None, None, 0)
 
-    def summary(self):
+    def summary(self, step_phase=None, loss_phase=None):
+        """``step_phase`` / ``loss_phase``: phase of tools/pmc_step.py whose launch has this run's shape (or None)."""
         torch.cuda.synchronize()
         mean_ms, min_ms, n = self._stats(self.step_events)
         if not n:
@@ -162,12 +188,12 @@ class KernelTimer:
         nbytes = STEP_BYTES_PER_ELEM * self.step_numel
         gbs = nbytes / mean_ms / 1e6
         step = dict(kernel="vqa_linf_step (stream4_kernel<StepOp>)", bound="hbm", achieved=round(gbs, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                    traffic=None, traffic_source=PMC_SUMMARY, launches=n,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                     mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
                     algorithmic_bytes_per_launch=nbytes,
                     timing="hip events on the launch stream, per launch; HBM traffic is not measured in this run "
-                           "(separate rocprofv3 --pmc passes, summary in traffic_source)")
+                           "(separate rocprofv3 --pmc passes, summary in traffic_source)",
+                    **traffic_fields(step_phase, "StepOp", "the same launch shape, back-to-back"))
         loss = None
         mean_ms, min_ms, n = self._stats(self.loss_events)
         if n:
@@ -178,9 +204,12 @@ class KernelTimer:
                                "launch, loss folded in the launch)", bound="hbm", achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
-                        algorithmic_bytes_per_launch=round(total_bytes / n), traffic=None, traffic_source=PMC_SUMMARY,
+                        algorithmic_bytes_per_launch=round(total_bytes / n),
                         note="12*D bytes per live row (read a, b; write grad); padded text rows are neither read nor "
-                             "counted")
+                             "counted",
+                        **traffic_fields(loss_phase, "neg_cos_rows_kernel",
+                                         "the same live rows in the untrimmed 617-token layout: the 30 padded text rows "
+                                         "per sample and map add their zero gradient rows, +76.7 MB"))
         return step, loss
 
 
@@ -207,7 +236,22 @@ def step_kernel_microbench(batch, image_size, reps=40):
     gbs = nbytes / ms / 1e6
     return dict(kernel="vqa_linf_step", batch=batch, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), mean_launch_us=round(ms * 1e3, 2),
-                algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps))
+                algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps),
+                **traffic_fields({64: "step64", 256: "step256"}.get(batch) if image_size == 384 else None, "StepOp",
+                                 "the same launch"))
+
+
+def attention_traffic(batch, heads, seq, with_bias):
+    """Recorded HBM bytes of one forward + one backward call (phase `attn` of the tracked PMC summary: B=64, H=12,
+    S=587 with the shared bias slab -- the default bench shape), per kernel."""
+    if (batch, heads, seq, bool(with_bias)) != (64, 12, 587, True):
+        return dict(traffic=None, traffic_source=PMC_SUMMARY)
+    parts = {k: recorded_traffic("attn", k) for k in ("attn_fwd_kernel", "attn_delta_kernel", "attn_bwd_dkv_kernel",
+                                                      "attn_bwd_dq_from_ds_kernel")}
+    if any(v is None for v in parts.values()):
+        return dict(traffic=None, traffic_source=PMC_SUMMARY)
+    return dict(traffic=sum(parts.values()), traffic_kind="recorded", traffic_per_kernel=parts,
+                traffic_source="{} (phase attn: the same four launches)".format(PMC_SUMMARY))
 
 
 def attention_microbench(batch, heads, seq, with_bias, reps=10):
@@ -256,7 +300,7 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
     return dict(kernel="vqa_attn_fwd + vqa_attn_bwd (attn_fwd_kernel; attn_delta_kernel, attn_bwd_dkv_kernel, "
                        "attn_bwd_dq_from_ds_kernel)",
                 bound="mfma", achieved=round(tf, 1), peak=FP32_MFMA_PEAK_TFS, unit="TFLOP/s",
-                frac=round(tf / FP32_MFMA_PEAK_TFS, 4), traffic=None,
+                frac=round(tf / FP32_MFMA_PEAK_TFS, 4), **attention_traffic(batch, heads, seq, with_bias),
                 shape=dict(batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias)),
                 forward=dict(ms=round(ms_f, 3), achieved=round(tf_f, 1), frac=round(tf_f / FP32_MFMA_PEAK_TFS, 4)),
                 backward=dict(ms=round(ms_b, 3), achieved=round(tf_b, 1), frac=round(tf_b / FP32_MFMA_PEAK_TFS, 4)),
@@ -266,7 +310,7 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
                 note="saved scores and the dS^T workspace each cross HBM once each way ({:.2f} GB per direction)".format(
                     2 * 4 * batch * heads * ((seq + 127) // 128 * 128) * ((seq + 31) // 32 * 32) / 1e9),
                 timing="{} back-to-back launches per direction between two hip events (host launch gaps included); "
-                       "per-kernel durations inside the attack: profiles/r02/bench_b64_pgd40_summary.txt".format(reps))
+                       "per-kernel durations inside the attack: profiles/r03/bench_default_summary.txt".format(reps))
 
 
 def baseline_config(args):
@@ -410,7 +454,10 @@ def main():
         t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    roof, roof_loss = timer.summary()
+    full_shape = cfg.image_size == 384 and not args.joint and not args.dual
+    roof, roof_loss = timer.summary(
+        step_phase={64: "step64", 256: "step256"}.get(args.batch) if cfg.image_size == 384 else None,
+        loss_phase="cos13" if (full_shape and args.model == "vlmo_base" and args.batch == 64) else None)
     if rank == 0:
         log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 

@@ -296,3 +296,50 @@ def test_mixed_batch_of_feature_and_dual_samples_matches_per_sample_oracle(flavo
         same_px = (res.adv_images[s].cpu() == adv[0]).float().mean().item()
         assert same_px >= 0.99, (flavor, s, same_px)
     assert n_changed >= 1
+
+
+@pytest.mark.parametrize("with_words", [False, True])
+def test_albef_random_token_masking_on_matches_oracle_at_batch_1(with_words):
+    """ALBEF re-draws a random 15 % MLM mask inside EVERY white-box forward (model_pretrain.py:130-132, ``mask`` :309-332).
+    With the mask generator seeded identically on both sides and batch 1 -- the reference's own batch size -- the product
+    and the oracle issue the same sequence of draws (``Gen_ori_feats``, then one per PGD step, one drawn-and-ignored per
+    probe step, :85-104), so the attack must agree as closely as with masking off.  For batch > 1 the product draws one
+    (B, L) mask where the reference would draw B separate (1, L) masks: those runs are only statistically equivalent."""
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_tiny
+    cfg = albef_tiny(mlm_probability=0.5)            # half of the tokens: every forward really changes the text
+    cpu_model, gpu_model = FrozenAlbef(cfg, seed=3), FrozenAlbef(cfg, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(51)
+    image = torch.empty(1, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(image).uniform_(-0.125, 0.125, generator=g)
+    ids = IDS[1:2, :6]
+    masks = (ids != 0).long()
+    att = torch.zeros_like(ids, dtype=torch.bool)
+    if with_words:
+        att[0, [2, 4]] = True
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(AlbefAttackAdapters(gpu_model), "albef", gpu_model.embedding_tables(),
+                             AttackConfig(budget=10, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    proposals = None
+    if with_words:
+        proposals = text_update.propose_candidates(attack.adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att,
+                                                   threshold=0)
+    gpu_model.seed_masking(7)
+    res = attack.attack_batch(image.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    cpu_model.seed_masking(7)
+    adv, new_ids, losses = attack_loop.attack_one(AlbefRefAdapters, cpu_model, "albef", image, ids, masks,
+                                                  proposals[0] if with_words else None, sim, init_eta=eta, budget=10,
+                                                  sim_threshold=0.3)
+    assert res.adv_text_ids[0].cpu().tolist() == new_ids[0].tolist()
+    same = (res.adv_images[0].cpu() == adv[0]).float().mean().item()
+    assert same >= 0.99, same
+    got = np.array([v for block in res.loss_lists for v in block])
+    want = np.array([v for block in losses for v in block])
+    assert np.allclose(got, want, rtol=2e-4, atol=1e-5), (got, want)
+    # the masking really acted: the same attack with masking off takes another trajectory
+    off = FrozenAlbef(albef_tiny(mlm_probability=0.0), seed=3).to(DEV)
+    res_off = BatchedVQAttack(AlbefAttackAdapters(off), "albef", off.embedding_tables(),
+                              AttackConfig(budget=10, sim_threshold=0.3), similarity_fn=sim).attack_batch(
+        image.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV), proposals=proposals)
+    assert (res_off.adv_images != res.adv_images).float().mean().item() > 0.01

@@ -150,15 +150,6 @@ def cos_section(b):
     report("vqa_neg_cos_rows_multi ({} layers, row weights)".format(n_layers), 12 * live * 768 * n_layers,
            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
                   reps=10))
-    # A/B: targets normalised once per attack -> the |b|^2 chain leaves the kernel (vqa_set_option(9, 1))
-    tn = [t / t.norm(dim=-1, keepdim=True).clamp_min(1e-6) for t in tl]
-    for bn, tgt in ((1, tn), (0, tl), (1, tn), (0, tl)):
-        assert _hip.lib().vqa_set_option(9, bn) == 0
-        report("vqa_neg_cos_rows_multi ({} layers, D=768) [targets {}]".format(
-            n_layers, "pre-normalised, no |b|^2 chain" if bn else "raw (shipped)"), 12 * rows * 768 * n_layers,
-            timeit(lambda: ops.neg_cos_rows_multi(al, tgt, slot, accumulate=False, ws=ws), reps=10), "A/B")
-    assert _hip.lib().vqa_set_option(9, 0) == 0
-    del tn
     for nt in (0, 5, 6, 7, 4):
         assert _hip.lib().vqa_set_option(8, nt) == 0
         report("vqa_neg_cos_rows_multi ({} layers, D=768) [nt mask {}: a loads {}, grad stores {}, b loads {}]".format(

@@ -32,6 +32,6 @@ for key in sorted(fetch):
     w = sum(v for v, _ in write.get(key, [(0, 0)])) / max(len(write.get(key, [])), 1)
     dur = sum(d for _, d in fetch[key]) / len(fetch[key])
     fetch_b, write_b = 2 * f * 1024, w * 1024
-    print("%-58s grid %9d  launches %d  FETCH_SIZE %.0f KiB (x2 -> %.1f MB)  WRITE_SIZE %.0f KiB (%.1f MB)  "
-          "HBM traffic %.1f MB  dur(profiled) %.1f us" % (key[0][:58], key[1], len(fetch[key]), f, fetch_b / 1e6, w,
+    print("%-96s grid %9d  launches %d  FETCH_SIZE %.0f KiB (x2 -> %.1f MB)  WRITE_SIZE %.0f KiB (%.1f MB)  "
+          "HBM traffic %.1f MB  dur(profiled) %.1f us" % (key[0][:96], key[1], len(fetch[key]), f, fetch_b / 1e6, w,
                                                          write_b / 1e6, (fetch_b + write_b) / 1e6, dur / 1e3))

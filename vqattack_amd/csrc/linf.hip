@@ -242,7 +242,6 @@ int vqa_set_option(int option, int value) {
     case 6:
     case 7:
     case 8:
-    case 9:
       return vqa_loss_set_option(option, value);
     default:
       return VQA_ERR_SHAPE;

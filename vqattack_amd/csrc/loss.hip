@@ -96,10 +96,10 @@ __device__ __forceinline__ void load_row(RowRegs<NCH>& r, const Cursor& c, const
 }
 
 // -cos of one row (added to acc) and, with GRAD, d(-cos)/da written to the gradient row.
-// BN (A/B experiment, vqa_set_option(9, 1)): the caller promises targets that are already b / max(|b|, eps) -- they
-// are constant over the iterations of an attack -- so the |b|^2 chain (D FMAs + one wave reduction + one sqrt per row)
-// is dropped.  The measured effect is recorded in DESIGN.md section 4 (profiles/r03/loss_bnorm_ab.jsonl).
-template <int NCH, bool GRAD, int NT, bool BN = false>
+// (Round 3 A/B: with targets normalised once per attack the |b|^2 chain -- D FMAs, one wave reduction, one sqrt per row --
+// can leave this function; measured 862-867 us against 853-854 us for the 13-map launch, i.e. no gain: the kernel waits
+// for HBM, not for the vector ALU.  profiles/r03/kernel_roofline_cos_ce_b64.jsonl; not shipped.)
+template <int NCH, bool GRAD, int NT>
 __device__ __forceinline__ void reduce_row(const RowRegs<NCH>& r, float& acc, int lane, int D, float gscale,
                                            float cos_eps) {
   const bool live = r.w != 0.0f;
@@ -111,15 +111,15 @@ __device__ __forceinline__ void reduce_row(const RowRegs<NCH>& r, float& acc, in
       for (int e = 0; e < 4; ++e) {
         dot += r.a[k][e] * r.b[k][e];
         na2 += r.a[k][e] * r.a[k][e];
-        if (!BN) nb2 += r.b[k][e] * r.b[k][e];
+        nb2 += r.b[k][e] * r.b[k][e];
       }
     }
     dot = wave_sum(dot);
     na2 = wave_sum(na2);
-    if (!BN) nb2 = wave_sum(nb2);
+    nb2 = wave_sum(nb2);
   }
-  const float na = sqrtf(na2), nb = BN ? 1.0f : sqrtf(nb2);
-  const float dna = fmaxf(na, cos_eps), dnb = BN ? 1.0f : fmaxf(nb, cos_eps);
+  const float na = sqrtf(na2), nb = sqrtf(nb2);
+  const float dna = fmaxf(na, cos_eps), dnb = fmaxf(nb, cos_eps);
   const float inv = 1.0f / (dna * dnb);
   if (live) acc += -(r.w * (dot * inv));
   if (GRAD) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ float block_sum_ordered(const float* p, int count, fl
   return s;
 }
 
-template <int NCH, bool GRAD, bool PIPE2, int NT, bool BN = false>
+template <int NCH, bool GRAD, bool PIPE2, int NT>
 __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(LayerTable tab, float* __restrict__ partial, Fold fold,
                                                               const uint8_t* __restrict__ row_mask, RowAddr ra,
                                                               int D, float gscale, float cos_eps) {
@@ -185,17 +185,17 @@ __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(LayerTable tab, fl
       load_row<NCH, NT>(r0, c, tab, ra, row_mask, lane, D);
       while (true) {                                          // two rows in flight, registers ping-pong r0 / r1
         if (left > 1) { advance(c, ra); load_row<NCH, NT>(r1, c, tab, ra, row_mask, lane, D); }
-        reduce_row<NCH, GRAD, NT, BN>(r0, acc, lane, D, gscale, cos_eps);
+        reduce_row<NCH, GRAD, NT>(r0, acc, lane, D, gscale, cos_eps);
         if (--left == 0) break;
         if (left > 1) { advance(c, ra); load_row<NCH, NT>(r0, c, tab, ra, row_mask, lane, D); }
-        reduce_row<NCH, GRAD, NT, BN>(r1, acc, lane, D, gscale, cos_eps);
+        reduce_row<NCH, GRAD, NT>(r1, acc, lane, D, gscale, cos_eps);
         if (--left == 0) break;
       }
     } else {
       RowRegs<NCH> r0;
       for (; left > 0; --left) {
         load_row<NCH, NT>(r0, c, tab, ra, row_mask, lane, D);
-        reduce_row<NCH, GRAD, NT, BN>(r0, acc, lane, D, gscale, cos_eps);
+        reduce_row<NCH, GRAD, NT>(r0, acc, lane, D, gscale, cos_eps);
         if (left > 1) advance(c, ra);
       }
     }
@@ -238,13 +238,11 @@ static int g_loss_blocks_per_cu = 0;   // vqa_set_option(6, n): 0 = exactly the 
 static int g_loss_rows_in_flight = 2;  // vqa_set_option(7, 1 | 2)
 static int g_loss_nt = 4;              // vqa_set_option(8, mask): bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b
 
-static int g_loss_b_normalised = 0;    // vqa_set_option(9, 0 | 1): A/B experiment, see reduce_row
-
-template <int NCH, bool GRAD, bool PIPE2, int NT, bool BN = false>
+template <int NCH, bool GRAD, bool PIPE2, int NT>
 static int launch_cos_inst(hipStream_t st, const LayerTable& tab, float* partial, const Fold& fold, const uint8_t* mask,
                            RowAddr ra, int D, float gscale, float eps) {
   static int occupancy_grid = 0;      // per instantiation: occupancy x CUs
-  if (occupancy_grid == 0) occupancy_grid = resident_blocks(neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT, BN>, kBlock, 6);
+  if (occupancy_grid == 0) occupancy_grid = resident_blocks(neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT>, kBlock, 6);
   int resident = g_loss_blocks_per_cu > 0 ? g_loss_blocks_per_cu * cu_count() : occupancy_grid;
   if (resident > kLossMaxBlocks) resident = kLossMaxBlocks;
   const long total = static_cast<long>(ra.rows0) * ra.rows1 * ra.n_layers;
@@ -258,7 +256,7 @@ static int launch_cos_inst(hipStream_t st, const LayerTable& tab, float* partial
     ra.step_o = static_cast<int>(so % ra.rows0);
     ra.step_l = static_cast<int>(so / ra.rows0);
   }
-  neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT, BN><<<grid, kBlock, 0, st>>>(tab, partial, fold, mask, ra, D, gscale, eps);
+  neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT><<<grid, kBlock, 0, st>>>(tab, partial, fold, mask, ra, D, gscale, eps);
   return launch_status();
 }
 
@@ -268,7 +266,6 @@ static int launch_cos(bool grad, hipStream_t st, const LayerTable& tab, float* p
 #define VQA_COS_GO(G, P, N) launch_cos_inst<NCH, G, P, N>(st, tab, partial, fold, mask, ra, D, gscale, eps)
   if (!grad) return g_loss_rows_in_flight == 2 ? VQA_COS_GO(false, true, 4) : VQA_COS_GO(false, false, 4);
   if (g_loss_rows_in_flight != 2) return VQA_COS_GO(true, false, 4);
-  if (g_loss_b_normalised) return launch_cos_inst<NCH, true, true, 4, true>(st, tab, partial, fold, mask, ra, D, gscale, eps);
   switch (g_loss_nt) {          // A/B knob of the loss + gradient kernel (two rows in flight)
     case 0: return VQA_COS_GO(true, true, 0);
     case 5: return VQA_COS_GO(true, true, 5);
@@ -325,11 +322,7 @@ extern "C" {
 
 int vqa_neg_cos_partials(void) { return kLossMaxBlocks + kArriveWords; }   // partials + the arrival counters
 
-int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_option(6 | 7 | 8 | 9, value)
-  if (which == 9) {
-    g_loss_b_normalised = value ? 1 : 0;
-    return VQA_OK;
-  }
+int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_option(6 | 7 | 8, value)
   if (which == 6) {
     if (value < 0 || value > 8) return VQA_ERR_SHAPE;
     g_loss_blocks_per_cu = value;
