@@ -33,6 +33,9 @@ def init_distributed():
 def finish(rank, world, result, out_json=None):
     if rank == 0:
         print("acc_vqa", result["asr"], result["n_total"], flush=True)     # the reference's final print (vlmo_module.py:2122)
+        print("sweep", json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in result.items()
+                                   if k in ("n_local", "seconds", "examples_per_sec_local", "gradient_steps", "n_batches",
+                                            "mean_batch", "collectives")}), flush=True)
         if out_json:
             with open(out_json, "w") as f:
                 json.dump(result["adv_text"], f)

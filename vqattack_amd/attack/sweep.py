@@ -98,6 +98,11 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     t0 = time.perf_counter()
     for key, local in buckets.items():
         n_words, is_dual = key // 2, bool(key % 2)
+        if key == -2:
+            # a mixed batch runs as many global steps as its longest sample needs and finished samples leave the white-box
+            # batch: batches of similar length waste the fewest slots.  Samples are independent, so the order is free
+            # (the ledger records sample ids); equal lengths keep the loss modes together.
+            local = sorted(local, key=lambda j: (-int(att[mine[j]].sum()), bool(dual[mine[j]]), j))
         for lo in range(0, len(local), batch):
             qids = [mine[j] for j in local[lo:lo + batch]]
             images = synthetic_images(qids, image_size, device)
