@@ -323,6 +323,46 @@ def test_albef_base_batch_with_substitution_matches_per_sample_oracle():
         np.testing.assert_allclose(got, want, rtol=1e-4)
 
 
+def test_vlmo_large_mixed_feature_and_dual_batch_matches_per_sample_oracle():
+    """BASELINE configs[4] shape, the most heterogeneous batch the drivers take: VLMO-large (25 maps per loss launch,
+    D = 1024), sample 0 feature loss with 2 substitutable words, sample 1 dual loss (3-d labels, two-piece answer) with
+    1 substitutable word, attacked as ONE batch through ``attack_mixed`` -- one encoder pass per global step with the
+    paraphrase as sample 1's text on its MLM steps, the 1024 x 30 522 MLM head at its live label rows only -- against
+    each sample's own batch-1 oracle loop (vlmo_module.py:1943-2055, dual blocks :2009-2035)."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import VlmoRefAdapters
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_large
+    budget = 6
+    cpu_model = FrozenVlmo(vlmo_large(384), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, img, eta = _inputs([6, 5], 40, seed=6)
+    att = torch.zeros_like(ids, dtype=torch.bool)
+    att[0, 1:3] = True
+    att[1, 2] = True
+    tasks, oracle_tasks = _dual_tasks("vlmo", ids, 40)
+    tasks, oracle_tasks = [None, tasks[1]], [None, oracle_tasks[1]]
+    adapters = VlmoAttackAdapters(gpu_model)
+    proposals = text_update.propose_candidates(adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att, threshold=0)
+    assert [len(p) for p in proposals] == [2, 1]
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(adapters, "vlmo", gpu_model.embedding_tables(),
+                             AttackConfig(budget=budget, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    res = attack.attack_mixed(img.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals, tasks=tasks)
+    assert res.gradient_steps == (budget + 2) + (budget + 1)
+    n_changed = 0
+    for s in range(2):
+        adv, new_ids, _ = attack_loop.attack_one(VlmoRefAdapters, cpu_model, "vlmo", img[s:s + 1], ids[s:s + 1],
+                                                 masks[s:s + 1], proposals[s], sim, init_eta=eta[s:s + 1], budget=budget,
+                                                 sim_threshold=0.3, task=oracle_tasks[s])
+        assert res.adv_text_ids[s].cpu().tolist() == new_ids[0].tolist(), s
+        n_changed += int((new_ids[0] != ids[s]).sum())
+        _compare(res.adv_images[s].cpu(), adv[0].detach(), budget + 2, full_attack=False)
+    assert n_changed >= 1, "the case should exercise at least one accepted substitution"
+
+
 def test_vlmo_base_attack_is_bitwise_reproducible():
     """Two runs of the same attack give the same bits: no kernel of the path accumulates with float atomics (loss fold
     in index order, two-stage per-sample reductions, attention backward without atomics), so a result can be compared
