@@ -241,6 +241,26 @@ def step_kernel_microbench(batch, image_size, reps=40):
                                  "the same launch"))
 
 
+def copy_probe(nbytes=906 << 20, reps=10):
+    """What a plain device copy reaches on THIS box at a footprint beyond the 256 MB Infinity Cache (read + write =
+    2 x nbytes ~ the step kernel's 1.8 GB at batch 256): the platform's streaming rate, to be read next to the 8 TB/s
+    spec the fractions are priced against."""
+    src = torch.empty(nbytes // 4, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2 * nbytes / (e0.elapsed_time(e1) / reps) / 1e6
+    return dict(kernel="torch.Tensor.copy_ (device to device)", footprint_bytes=2 * nbytes, achieved=round(gbs, 1),
+                unit="GB/s", frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
+
+
 def attention_traffic(batch, heads, seq, with_bias):
     """Recorded HBM bytes of one forward + one backward call (phase `attn` of the tracked PMC summary: B=64, H=12,
     S=587 with the shared bias slab -- the default bench shape), per kernel."""
@@ -490,6 +510,7 @@ def main():
         }
         if not args.no_b256:
             try:
+                line["platform_copy_probe"] = copy_probe()
                 line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
             except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
                 line["roofline_b256"] = {"error": str(exc)[:200]}

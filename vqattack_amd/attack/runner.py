@@ -340,19 +340,19 @@ class BatchedVQAttack:
         losses = torch.zeros(max(total), dtype=torch.float32, device=dev)
         ws = ops.Workspace()
         res = BatchResult(adv_images=cur, adv_text_ids=adv_ids)
-        text_key, text_cache, version = None, {}, 0                       # (active samples, who is at an MLM step, text edit)
+        text_key, text_cache, version, sel = None, {}, 0, None            # (active samples, who is at an MLM step, text edit)
         for t in range(max(total)):
             n_act = sum(1 for x in total if x > t)
             now = [kinds[s][t][0] for s in range(n_act)]
             at_mlm = tuple(s for s in range(n_act) if now[s] == "M")
             key = (n_act, at_mlm, version)
             if key != text_key:
+                sel = torch.tensor(at_mlm, device=dev) if at_mlm else None      # who takes an MLM step, as a device index
                 if key in text_cache:
                     a.load_text(text_cache[key])
                 else:
                     ids_t, masks_t = adv_ids[:n_act], text_masks[:n_act]
                     if at_mlm:
-                        sel = torch.tensor(at_mlm, device=dev)
                         ids_t, masks_t = ids_t.clone(), masks_t.clone()
                         ids_t[sel], masks_t[sel] = mlm_ids[sel], mlm_mask[sel]
                     a.set_text(ids_t, masks_t, text_len=pinned)
@@ -361,7 +361,7 @@ class BatchedVQAttack:
                             text_cache.pop(next(iter(text_cache)))
                         text_cache[key] = a.save_text()
                 if any_dual:
-                    a.set_mlm_samples(torch.tensor(at_mlm, device=dev) if at_mlm else None)
+                    a.set_mlm_samples(sel)
                 y = [v.rows(n_act) if isinstance(v, LayerFeatures) else (None if v is None else v[:n_act])
                      for v in self._y_feature(targets)]
                 text_key = key
@@ -369,14 +369,13 @@ class BatchedVQAttack:
             emb_t = adv_emb[:n_act]
             if at_mlm:
                 emb_t = emb_t.clone()
-                sel = torch.tensor(at_mlm, device=dev)
                 emb_t[sel] = emb_mlm[sel]
             leaf_txt = emb_t.detach().requires_grad_(True)
             slot = attacks._LossSlot(losses, t)
             if any_dual:
                 attacks._mixed_loss_and_grad(a.pgd_attack_mixed, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y),
                                              self.flavor, slot, ws=ws, flag=flag,
-                                             mlm_labels=labels_live[torch.tensor(at_mlm, device=dev)] if at_mlm else None)
+                                             mlm_labels=labels_live[sel] if at_mlm else None)
             else:
                 attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1,
                                        self.flavor, False, slot, vl=True, ws=ws)
