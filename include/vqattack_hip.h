@@ -196,7 +196,10 @@ int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate
  * exp() is the hardware exponential (v_exp_f32, ~2 ulp); parity with torch is stated as 1e-4 relative in the tests.
  * Replaces F.cross_entropy(out[0].view(-1, 30522), y[0][...].view(-1), ignore_index=-100), its K-fold repetition for
  * 3-d labels and the autograd backward: A-ch/attacks/fast_gradient_method.py:131-142, V-ch/...:115-126.
- * Algorithmic bytes: 8*V per row (read the logits once from HBM, write the gradient once). */
+ * A row whose K labels are all ignore_index -- every position but the [MASK]-ed answer pieces in the reference's
+ * workload, ALBEF_attack/adv_attack.py:433-558 -- has zero loss and a zero gradient whatever its logits are: they are not
+ * read and no exponential is evaluated; the row costs its zero gradient store.
+ * Algorithmic bytes: 8*V per live row (read the logits once from HBM, write the gradient once), 4*V per dead row. */
 int vqa_ce_max_label_sets(void);
 long vqa_ce_scratch_floats(int K, long groups);
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
