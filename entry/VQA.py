@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--n_samples", default=None, type=int)
     ap.add_argument("--image_only", action="store_true", help="no word substitution (40-step image PGD)")
     ap.add_argument("--tiny", action="store_true", help="test-sized encoder")
+    ap.add_argument("--dual_every", default=0, type=int,
+                    help="every n-th synthetic sample's victim answer occurs in its paraphrase -> dual loss (old_alg == 0)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="one bucket: batches mix schedules and loss modes (attack_mixed) instead of schedule-pure buckets")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
     rank, world, device = init_distributed()
@@ -35,7 +39,8 @@ def main():
     res = run_sweep("albef", white, black, AlbefAttackAdapters(white), args.n_samples or cfg["n_samples"],
                     cfg["batch_size_test"], mcfg.image_size, min(cfg["text_len"], 8 if args.tiny else 512), device,
                     rank, world, joint=not args.image_only, save_dir=out_dir, seed=args.seed,
-                    max_words=4 if args.tiny else 12, force_collective=dist.is_initialized())
+                    max_words=4 if args.tiny else 12, dual_every=args.dual_every, mixed=args.mixed,
+                    force_collective=dist.is_initialized())
     finish(rank, world, res, os.path.join(args.output_dir, "adv_txt.json") if args.output_dir else None)
 
 

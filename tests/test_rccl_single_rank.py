@@ -54,6 +54,15 @@ def _entry_rank(port, out_path, argv):
     sys.stdout.flush()
 
 
+def _entry_vqa_rank(port, out_path, argv):
+    _as_torchrun_rank(port, out_path)
+    sys.path.insert(0, os.path.join(ROOT, "entry"))
+    sys.argv = ["VQA.py"] + list(argv)
+    import VQA
+    VQA.main()
+    sys.stdout.flush()
+
+
 def _run(target, args):
     ctx = multiprocessing.get_context("forkserver")
     p = ctx.Process(target=target, args=args)
@@ -96,3 +105,24 @@ def test_entry_run_single_rank_over_rccl(tmp_path):
     assert len(info) == 1, text[-2000:]
     parts = info[0].split()
     assert parts[1] == "nccl" and parts[3] == "1" and int(parts[5]) >= 2
+
+
+def test_entry_vqa_single_rank_over_rccl(tmp_path):
+    """The ALBEF-flavor entry point (argparse + yaml like ALBEF_attack/VQA.py:119-134) through the same launch path, with
+    a mixed sweep (feature and dual-loss samples of different schedules in one batch) and the .pt / json outputs."""
+    out = str(tmp_path / "vqa.out")
+    code = _run(_entry_vqa_rank, (_free_port(), out, ["--tiny", "--n_samples", "6", "--dual_every", "3", "--mixed",
+                                                       "--output_dir", str(tmp_path)]))
+    text = open(out).read()
+    assert code == 0, text[-2000:]
+    lines = text.splitlines()
+    acc = [ln for ln in lines if ln.startswith("acc_vqa")]
+    assert len(acc) == 1 and acc[0].split()[2] == "6"
+    info = [ln for ln in lines if ln.startswith("dist_backend")]
+    assert len(info) == 1 and info[0].split()[1] == "nccl", text[-2000:]
+    sweep = json.loads([ln for ln in lines if ln.startswith("sweep ")][0][len("sweep "):])
+    assert sweep["n_local"] == 6 and sweep["n_batches"] >= 1 and sweep["collectives"] >= 2
+    adv = json.load(open(os.path.join(str(tmp_path), "adv_txt.json")))
+    assert sorted(map(int, adv)) == list(range(6))
+    pts = [f for _, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith(".pt")]
+    assert len(pts) == 6
