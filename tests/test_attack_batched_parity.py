@@ -343,3 +343,41 @@ def test_albef_random_token_masking_on_matches_oracle_at_batch_1(with_words):
                               AttackConfig(budget=10, sim_threshold=0.3), similarity_fn=sim).attack_batch(
         image.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV), proposals=proposals)
     assert (res_off.adv_images != res.adv_images).float().mean().item() > 0.01
+
+
+def test_albef_random_token_masking_on_in_mixed_batches_matches_oracle_at_batch_1():
+    """``attack_mixed`` feeds text EMBEDDINGS on every step, so the per-forward random token masking of the id-taking
+    closures (``Gen_feats`` / ``get_mlm_logits``, model_pretrain.py:130-132,105-122) is applied by the driver: freshly masked
+    ids are embedded for every sample that is not at a probe step (the probe closure ignores its draw, :85-104).  At batch 1
+    the draws line up one to one with the reference-structured oracle loop: same seed, same attack."""
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_tiny
+    cfg = albef_tiny(mlm_probability=0.5)
+    cpu_model, gpu_model = FrozenAlbef(cfg, seed=3), FrozenAlbef(cfg, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(61)
+    image = torch.empty(1, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    eta = torch.empty_like(image).uniform_(-0.125, 0.125, generator=g)
+    ids = IDS[1:2, :6]
+    masks = (ids != 0).long()
+    att = torch.zeros_like(ids, dtype=torch.bool)
+    att[0, [2, 4]] = True
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+    attack = BatchedVQAttack(AlbefAttackAdapters(gpu_model), "albef", gpu_model.embedding_tables(),
+                             AttackConfig(budget=10, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+    proposals = text_update.propose_candidates(attack.adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att,
+                                               threshold=0)
+    gpu_model.seed_masking(9)
+    res = attack.attack_mixed(image.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                              proposals=proposals)
+    cpu_model.seed_masking(9)
+    adv, new_ids, _ = attack_loop.attack_one(AlbefRefAdapters, cpu_model, "albef", image, ids, masks, proposals[0], sim,
+                                             init_eta=eta, budget=10, sim_threshold=0.3)
+    assert res.adv_text_ids[0].cpu().tolist() == new_ids[0].tolist()
+    same = (res.adv_images[0].cpu() == adv[0]).float().mean().item()
+    assert same >= 0.99, same
+    # and the masking acted: with the same seed but masking off the trajectory differs
+    off = FrozenAlbef(albef_tiny(mlm_probability=0.0), seed=3).to(DEV)
+    res_off = BatchedVQAttack(AlbefAttackAdapters(off), "albef", off.embedding_tables(),
+                              AttackConfig(budget=10, sim_threshold=0.3), similarity_fn=sim).attack_mixed(
+        image.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV), proposals=proposals)
+    assert (res_off.adv_images != res.adv_images).float().mean().item() > 0.01

@@ -341,6 +341,12 @@ class BatchedVQAttack:
         ws = ops.Workspace()
         res = BatchResult(adv_images=cur, adv_text_ids=adv_ids)
         text_key, text_cache, version, sel = None, {}, 0, None            # (active samples, who is at an MLM step, text edit)
+        # ALBEF re-draws a random MLM mask inside every forward that takes token ids (Gen_feats / get_mlm_logits,
+        # model_pretrain.py:130-132,105-122); the probe closure takes embeddings and ignores its draw (:85-104).  Every step
+        # here feeds embeddings, so the ids are masked per step and embedded for all samples that are not probing.
+        masker = getattr(a, "mask_text_ids", None) if getattr(a, "random_masking", False) else None
+        use_mixed_closure = hasattr(a, "pgd_attack_mixed")     # draws no mask of its own; else the plain probe closure
+        ids_step = None
         for t in range(max(total)):
             n_act = sum(1 for x in total if x > t)
             now = [kinds[s][t][0] for s in range(n_act)]
@@ -349,17 +355,19 @@ class BatchedVQAttack:
             if key != text_key:
                 sel = torch.tensor(at_mlm, device=dev) if at_mlm else None      # who takes an MLM step, as a device index
                 if key in text_cache:
-                    a.load_text(text_cache[key])
+                    state, ids_step = text_cache[key]
+                    a.load_text(state)
                 else:
                     ids_t, masks_t = adv_ids[:n_act], text_masks[:n_act]
                     if at_mlm:
                         ids_t, masks_t = ids_t.clone(), masks_t.clone()
                         ids_t[sel], masks_t[sel] = mlm_ids[sel], mlm_mask[sel]
                     a.set_text(ids_t, masks_t, text_len=pinned)
+                    ids_step = ids_t
                     if any_dual:                                          # dual iterations alternate between two texts
                         if len(text_cache) >= 2:
                             text_cache.pop(next(iter(text_cache)))
-                        text_cache[key] = a.save_text()
+                        text_cache[key] = (a.save_text(), ids_step)
                 if any_dual:
                     a.set_mlm_samples(sel)
                 y = [v.rows(n_act) if isinstance(v, LayerFeatures) else (None if v is None else v[:n_act])
@@ -370,9 +378,16 @@ class BatchedVQAttack:
             if at_mlm:
                 emb_t = emb_t.clone()
                 emb_t[sel] = emb_mlm[sel]
+            if masker is not None:
+                emb_m = ops.embed_tokens(self.tables, masker(ids_step))   # one draw per step, like one per forward
+                probing = [s for s in range(n_act) if kinds[s][t][1]]
+                if probing:                                               # probe steps see the unmasked embeddings
+                    idx = torch.tensor(probing, device=dev)
+                    emb_m[idx] = emb_t[idx]
+                emb_t = emb_m
             leaf_txt = emb_t.detach().requires_grad_(True)
             slot = attacks._LossSlot(losses, t)
-            if any_dual:
+            if use_mixed_closure:
                 attacks._mixed_loss_and_grad(a.pgd_attack_mixed, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y),
                                              self.flavor, slot, ws=ws, flag=flag,
                                              mlm_labels=labels_live[sel] if at_mlm else None)

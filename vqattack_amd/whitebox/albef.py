@@ -356,6 +356,16 @@ class AlbefAttackAdapters:
         """Batch indices (int64 device tensor) of the samples taking an MLM step in the next ``pgd_attack_mixed`` calls."""
         self._mlm_samples = None if index is None or index.numel() == 0 else index
 
+    @property
+    def random_masking(self):
+        """True: the white box re-draws a random MLM mask over the text in every forward that takes token ids
+        (model_pretrain.py:130-132) -- a driver that feeds text EMBEDDINGS on such steps has to embed masked ids."""
+        return self.model.cfg.mlm_probability > 0
+
+    def mask_text_ids(self, text_ids):
+        """One draw of the reference's ``mask`` (model_pretrain.py:309-332) over a batch of token ids."""
+        return self.model.mask_tokens(text_ids)
+
     def save_text(self):
         return (dict(self.batch), self._tlen, self._weight)
 
