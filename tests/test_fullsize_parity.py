@@ -214,7 +214,7 @@ def test_vlmo_base_ragged_batch_with_mixed_schedules_matches_per_sample_oracle()
     got_clean = black_gpu.vqa_answer(img.to(DEV), ids.to(DEV), masks.to(DEV)).cpu().tolist()
     got_after = black_gpu.vqa_answer(res.adv_images, res.adv_text_ids, masks.to(DEV)).cpu().tolist()
     del black_gpu
-    assert got_clean == want_clean
+    assert got_clean == want_clean and got_after == want_after      # the victim's answers, hence the success bits
     assert [int(a != c) for a, c in zip(got_after, got_clean)] == [int(a != c) for a, c in zip(want_after, want_clean)]
     # losses: the oracle loop does not report the loss of a probe step, so the batch trajectory is compared on a second,
     # image-only run of the same four questions (every step of every sample is then reported on both sides)

@@ -11,7 +11,7 @@ success rate within +-0.5 % of the reference's.  Here, for the same seeded sampl
             per-question CPU scorers (``oracle/blackbox_ref``, ``rank_answer`` pinned by the reference's method).
 
 Required: the two success-bit vectors are EQUAL (a disagreement budget of 0.5 % of 32 samples is zero samples), the
-clean answers are equal, and the set is informative (both outcomes occur).  Perturbations that differ in < 1 % of the
+clean answers and the answers to the adversarial pairs are equal, and the set is informative (both outcomes occur).  Perturbations that differ in < 1 % of the
 pixels by 2 * eps_iter (sign flips of ~0 gradients, see test_fullsize_parity) must not move a decision; the margins of
 the oracle's decisions are printed so that a failure can be told from a borderline sample.
 """
@@ -176,6 +176,9 @@ def test_success_bits_equal_oracle_pipeline(flavor):
     assert torch.equal(torch.cat(got_ids), adv_ids), "substituted token ids differ"
     assert got_bits == bits, [(s, got_after[s], after[s], margins[s]) for s in range(N_SAMPLES)
                               if got_bits[s] != bits[s]]
+    # stronger than the bits: the victim's ANSWER to every adversarial pair is the same on both sides
+    assert got_after == after, [(s, got_after[s], after[s], margins[s]) for s in range(N_SAMPLES)
+                                if got_after[s] != after[s]]
     assert 0 < sum(bits) < N_SAMPLES, "the sample set should contain successes and failures"
 
 
