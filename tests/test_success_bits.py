@@ -11,9 +11,10 @@ success rate within +-0.5 % of the reference's.  Here, for the same seeded sampl
             per-question CPU scorers (``oracle/blackbox_ref``, ``rank_answer`` pinned by the reference's method).
 
 Required: the two success-bit vectors are EQUAL (a disagreement budget of 0.5 % of 32 samples is zero samples), the
-clean answers and the answers to the adversarial pairs are equal, and the set is informative (both outcomes occur).  Perturbations that differ in < 1 % of the
-pixels by 2 * eps_iter (sign flips of ~0 gradients, see test_fullsize_parity) must not move a decision; the margins of
-the oracle's decisions are printed so that a failure can be told from a borderline sample.
+clean answers and the answers to the adversarial pairs are equal, and the set is informative (both outcomes occur).
+Perturbations that differ in < 1 % of the pixels by 2 * eps_iter (sign flips of ~0 gradients, see test_fullsize_parity)
+must not move a decision; the margins of the oracle's decisions are printed so that a failure can be told from a
+borderline sample.
 """
 import contextlib
 
