@@ -287,29 +287,11 @@ class BatchedVQAttack:
         if any_dual and not hasattr(a, "pgd_attack_mixed"):
             raise ValueError("dual-loss samples in attack_mixed need adapters with pgd_attack_mixed()")
         # ---- MLM side of the dual-loss samples: paraphrase ids / masks, labels, live label rows (fixed for the attack)
-        mlm_ids = mlm_mask = labels_live = emb_mlm = None
+        mlm_ids = mlm_mask = labels = labels_live = emb_mlm = None
         if any_dual:
-            tasks = [mlm_task.MlmTask(**vars(tasks[s])) if is_dual[i] else None for i, s in enumerate(order)]
-            for t in tasks:
-                if t is not None:
-                    t.words_mlm = list(t.words_mlm)                       # private copies: update_mlm_text edits them
-            width = max([text_ids.shape[1]] + [len(t.text_ids_mlm) for t in tasks if t is not None])
-            if width > text_ids.shape[1]:          # ALBEF encodes a paraphrase at its own length (padding='longest')
-                grow = (0, width - text_ids.shape[1])
-                text_ids, text_masks = F.pad(text_ids, grow), F.pad(text_masks, grow)
-                attackable = F.pad(attackable, grow)
-            mlm_ids, mlm_mask = text_ids.clone(), text_masks.clone()
-            sets = [[] if t is None else (t.mlm_labels if isinstance(t.mlm_labels[0], list) else [t.mlm_labels])
-                    for t in tasks]
-            k = max(len(x) for x in sets)
-            labels = torch.full((b, k, width), mlm_task.IGNORE, dtype=torch.int64)
-            for s, t in enumerate(tasks):
-                if t is None:
-                    continue
-                self._write_mlm_row(mlm_ids, mlm_mask, s, t)
-                for j, row in enumerate(sets[s]):
-                    labels[s, j, :len(row)] = torch.tensor(row)
-            labels = (labels[:, 0] if k == 1 else labels).to(dev)
+            tasks = [tasks[s] if is_dual[i] else None for i, s in enumerate(order)]
+            tasks, text_ids, text_masks, attackable, mlm_ids, mlm_mask, labels = self._mixed_mlm_side(
+                tasks, text_ids, text_masks, attackable)
         if proposals is None:
             fn = mlm_logits_fn or getattr(a, "mlm_logits", None)
             proposals = text_update.propose_candidates(fn(text_ids, text_masks), text_ids, attackable,
@@ -394,18 +376,7 @@ class BatchedVQAttack:
             else:
                 attacks._loss_and_grad(a.pgd_attack_vl, [leaf_img, leaf_txt], [leaf_img, leaf_txt], list(y), 1,
                                        self.flavor, False, slot, vl=True, ws=ws)
-            grad = attacks._grad_of(leaf_img)
-            lo = 0
-            while lo < n_act:                                             # one fused update per run of equal kinds
-                hi = lo + 1
-                while hi < n_act and (now[hi] == "N") == (now[lo] == "N"):
-                    hi += 1
-                if now[lo] == "N":      # first half of a dual iteration: no projection in between (pgd :155-188)
-                    ops.linf_fgm(cur[lo:hi], grad[lo:hi], c.eps_iter, c.clip_min, c.clip_max, out=cur[lo:hi])
-                else:                   # in place: finished samples stay untouched
-                    ops.linf_step(cur[lo:hi], grad[lo:hi], images[lo:hi], c.eps_iter, c.eps, c.clip_min, c.clip_max,
-                                  out=cur[lo:hi])
-                lo = hi
+            self._update_runs(cur, attacks._grad_of(leaf_img), images, now)
             firing = [s for s in range(n_act) if kinds[s][t][1]]
             if firing:
                 sub = plan.restricted_to(firing)
@@ -417,17 +388,10 @@ class BatchedVQAttack:
                 ops.embed_tokens(self.tables, adv_ids, out=adv_emb)
                 version += 1
                 text_cache.clear()
-                if any_dual and any(is_dual[s] for s in firing):          # update_mlm_text (adv_attack.py:334-351)
-                    subs = text_update.substitution_lists(prev, new_id, rank)
-                    changed = False
-                    for s in firing:
-                        if is_dual[s] and subs[s]:
-                            mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in subs[s]])
-                            tasks[s].reencode()
-                            self._write_mlm_row(mlm_ids, mlm_mask, s, tasks[s])
-                            changed = True
-                    if changed:
-                        ops.embed_tokens(self.tables, mlm_ids, out=emb_mlm)
+                if any_dual and any(is_dual[s] for s in firing) and \
+                        self._follow_substitutions(tasks, [s for s in firing if is_dual[s]], mlm_ids, mlm_mask,
+                                                   text_update.substitution_lists(prev, new_id, rank)):
+                    ops.embed_tokens(self.tables, mlm_ids, out=emb_mlm)
         if c.sanity_checks:
             bits = int(flag.item())
             assert bits == 0, "input images are outside [clip_min, clip_max]" if bits & 1 else "bad MLM label"
@@ -441,6 +405,61 @@ class BatchedVQAttack:
         res.loss_lists = [losses.tolist()]
         res.gradient_steps = sum(total)
         return res
+
+    def _mixed_mlm_side(self, tasks, text_ids, text_masks, attackable):
+        """MLM side of a mixed batch (``tasks``: one ``MlmTask`` per dual-loss sample, None elsewhere, in batch order).
+        Returns private task copies, the text tensors widened to the longest paraphrase (ALBEF encodes a paraphrase at
+        its own length, ``padding='longest'``), the paraphrase ids / masks (a feature sample's row = its question) and the
+        labels (B, L) / (B, K, L) on the device (``ignore_index`` rows for feature samples and missing label sets)."""
+        dev, b = text_ids.device, text_ids.shape[0]
+        tasks = [None if t is None else mlm_task.MlmTask(**vars(t)) for t in tasks]
+        for t in tasks:
+            if t is not None:
+                t.words_mlm = list(t.words_mlm)                           # private copies: update_mlm_text edits them
+        width = max([text_ids.shape[1]] + [len(t.text_ids_mlm) for t in tasks if t is not None])
+        if width > text_ids.shape[1]:
+            grow = (0, width - text_ids.shape[1])
+            text_ids, text_masks, attackable = F.pad(text_ids, grow), F.pad(text_masks, grow), F.pad(attackable, grow)
+        mlm_ids, mlm_mask = text_ids.clone(), text_masks.clone()
+        sets = [[] if t is None else (t.mlm_labels if isinstance(t.mlm_labels[0], list) else [t.mlm_labels])
+                for t in tasks]
+        k = max(len(x) for x in sets)
+        labels = torch.full((b, k, width), mlm_task.IGNORE, dtype=torch.int64)
+        for s, t in enumerate(tasks):
+            if t is None:
+                continue
+            self._write_mlm_row(mlm_ids, mlm_mask, s, t)
+            for j, row in enumerate(sets[s]):
+                labels[s, j, :len(row)] = torch.tensor(row)
+        return tasks, text_ids, text_masks, attackable, mlm_ids, mlm_mask, (labels[:, 0] if k == 1 else labels).to(dev)
+
+    def _update_runs(self, cur, grad, images, now):
+        """The fused image update of one global step, in place on the active prefix of ``cur``: one launch per run of
+        consecutive samples of one kind -- ``vqa_linf_fgm`` for ``N`` (first half of a dual iteration: no projection in
+        between, projected_gradient_descent.py:155-188), ``vqa_linf_step`` otherwise.  Finished samples stay untouched."""
+        c, lo, n_act = self.cfg, 0, len(now)
+        while lo < n_act:
+            hi = lo + 1
+            while hi < n_act and (now[hi] == "N") == (now[lo] == "N"):
+                hi += 1
+            if now[lo] == "N":
+                ops.linf_fgm(cur[lo:hi], grad[lo:hi], c.eps_iter, c.clip_min, c.clip_max, out=cur[lo:hi])
+            else:
+                ops.linf_step(cur[lo:hi], grad[lo:hi], images[lo:hi], c.eps_iter, c.eps, c.clip_min, c.clip_max,
+                              out=cur[lo:hi])
+            lo = hi
+
+    def _follow_substitutions(self, tasks, samples, mlm_ids, mlm_mask, subs):
+        """``update_mlm_text`` (adv_attack.py:334-351) for the dual-loss ``samples`` that just probed: their paraphrase
+        takes over the question's substitutions ``subs[s]`` = [(position, old id, new id), ...].  True if any row changed."""
+        changed = False
+        for s in samples:
+            if subs[s]:
+                mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in subs[s]])
+                tasks[s].reencode()
+                self._write_mlm_row(mlm_ids, mlm_mask, s, tasks[s])
+                changed = True
+        return changed
 
     @staticmethod
     def _write_mlm_row(mlm_ids, mlm_mask, s, task):
