@@ -286,6 +286,9 @@ class BatchedVQAttack:
         any_dual = any(is_dual)
         if any_dual and not hasattr(a, "pgd_attack_mixed"):
             raise ValueError("dual-loss samples in attack_mixed need adapters with pgd_attack_mixed()")
+        if hasattr(a, "set_mlm_samples"):          # nothing of an earlier (possibly aborted) attack may linger
+            a.set_mlm_rows(None)
+            a.set_mlm_samples(None)
         # ---- MLM side of the dual-loss samples: paraphrase ids / masks, labels, live label rows (fixed for the attack)
         mlm_ids = mlm_mask = labels = labels_live = emb_mlm = None
         if any_dual:
