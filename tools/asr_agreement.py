@@ -1,0 +1,86 @@
+"""Attack-success-rate agreement of the product pipeline with the oracle pipeline on a LARGER seeded sample set than the
+tracked test (tests/test_success_bits.py, 32 per flavor): same sample generator, same pipelines, N samples per flavor.
+
+    python tools/asr_agreement.py [--n 512] [--flavors vlmo,albef]      -> one JSON line per flavor
+
+product = batched joint attack on the MI355X (attack_mixed, mixed schedules and loss modes, batches of 64) + batched
+black-box scorer; oracle = per-sample CPU loop (oracle/attack_loop.py) + per-question CPU scorers (oracle/blackbox_ref.py).
+The north star asks for an attack success rate within +-0.5 % of the reference path's on the same pairs.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import test_success_bits as tsb  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--flavors", default="vlmo,albef")
+    ap.add_argument("--batch", type=int, default=64)
+    args = ap.parse_args()
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    dev = torch.device("cuda", 0)
+    for flavor in args.flavors.split(","):
+        white, black, adapters_cls, ref_cls, cfg = tsb.build(flavor)
+        samples = tsb.make_samples(flavor, cfg, n=args.n, seed=11)
+        ids, masks, att, tasks, _, images, eta = samples
+        white_gpu, black_gpu = copy.deepcopy(white).to(dev), copy.deepcopy(black).to(dev)
+        sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+        attack = BatchedVQAttack(adapters_cls(white_gpu), flavor, white_gpu.embedding_tables(),
+                                 AttackConfig(budget=tsb.BUDGET, sim_threshold=0.3), similarity_fn=sim)
+        proposals = []
+        for lo in range(0, args.n, 256):
+            sl = slice(lo, lo + 256)
+            proposals += text_update.propose_candidates(attack.adapters.mlm_logits(ids[sl].to(dev), masks[sl].to(dev)),
+                                                        ids[sl], att[sl], threshold=0)
+        t0 = time.perf_counter()
+        got_clean, got_after, got_ids = [], [], []
+        for lo in range(0, args.n, args.batch):
+            sl = slice(lo, lo + args.batch)
+            got_clean += black_gpu.vqa_answer(images[sl].to(dev), ids[sl].to(dev), masks[sl].to(dev)).cpu().tolist()
+            res = attack.attack_mixed(images[sl].to(dev), ids[sl].to(dev), masks[sl].to(dev), att[sl].to(dev),
+                                      init_eta=eta[sl].to(dev), proposals=proposals[sl], tasks=tasks[sl])
+            got_after += black_gpu.vqa_answer(res.adv_images, res.adv_text_ids, masks[sl].to(dev)).cpu().tolist()
+            got_ids.append(res.adv_text_ids.cpu())
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        clean, after, bits, margins, adv_rows = [], [], [], [], []
+        for lo in range(0, args.n, 32):                  # in chunks: a line of progress every few seconds of CPU work
+            sl = slice(lo, lo + 32)
+            part = tuple(x[sl] for x in samples)
+            c_, a_, b_, m_, ids_ = tsb.oracle_pipeline(flavor, white, black, ref_cls, cfg, part, proposals[sl], sim)
+            clean, after, bits, margins = clean + c_, after + a_, bits + b_, margins + m_
+            adv_rows.append(ids_)
+            print("[asr_agreement] {} oracle {}/{} samples, {:.0f} s".format(flavor, min(lo + 32, args.n), args.n,
+                                                                            time.perf_counter() - t0),
+                  file=sys.stderr, flush=True)
+        adv_ids = torch.cat(adv_rows)
+        t_cpu = time.perf_counter() - t0
+        got_bits = [int(a != c) for a, c in zip(got_after, got_clean)]
+        differ = [s for s in range(args.n) if got_bits[s] != bits[s]]
+        print(json.dumps(dict(
+            flavor=flavor, n=args.n, dual_loss_samples=sum(t is not None for t in tasks),
+            product_asr=float(np.mean(got_bits)), oracle_asr=float(np.mean(bits)),
+            asr_difference=float(np.mean(got_bits) - np.mean(bits)), success_bit_disagreements=len(differ),
+            clean_answer_disagreements=sum(int(a != b) for a, b in zip(got_clean, clean)),
+            adversarial_answer_disagreements=sum(int(a != b) for a, b in zip(got_after, after)),
+            substituted_id_rows_differing=int((torch.cat(got_ids) != adv_ids).any(dim=1).sum()),
+            margins_of_disagreeing_samples=[round(margins[s], 6) for s in differ],
+            smallest_oracle_margins=[round(m, 6) for m in sorted(margins)[:5]],
+            seconds_product=round(t_gpu, 1), seconds_oracle=round(t_cpu, 1))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
