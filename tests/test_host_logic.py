@@ -227,3 +227,37 @@ def test_step_kinds_follow_the_reference_schedule():
                 assert dual[at] == ("F", True) and feat[at] == ("F", True)
                 at += 1
     assert [k for k, _ in BatchedVQAttack._step_kinds(0, 7, True)] == ["N", "M"] * 3      # int(7 / 2) dual iterations
+
+
+def test_mixed_update_runs_and_paraphrase_following(monkeypatch):
+    """Host logic of ``attack_mixed`` that needs no device: the fused update is launched once per run of consecutive
+    samples of one kind (``N`` = no projection -> vqa_linf_fgm; everything else -> vqa_linf_step), and a dual-loss
+    sample's paraphrase takes over the question's substitutions like ``update_mlm_text`` (adv_attack.py:334-351)."""
+    from vqattack_amd import ops
+    from vqattack_amd.attack import mlm_task
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    calls = []
+    monkeypatch.setattr(ops, "linf_fgm", lambda x, g, *a, **kw: calls.append(("fgm", x.shape[0], int(x[0, 0]))))
+    monkeypatch.setattr(ops, "linf_step", lambda x, g, x0, *a, **kw: calls.append(("step", x.shape[0], int(x[0, 0]))))
+    attack = BatchedVQAttack.__new__(BatchedVQAttack)
+    attack.cfg = AttackConfig()
+    cur = torch.arange(7, dtype=torch.float32).reshape(7, 1).repeat(1, 2)      # sample s is filled with s
+    attack._update_runs(cur, cur.clone(), cur.clone(), ["F", "F", "N", "N", "M", "N", "F"][:6])
+    assert calls == [("step", 2, 0), ("fgm", 2, 2), ("step", 1, 4), ("fgm", 1, 5)]   # the 7th sample is not active
+    calls.clear()
+    attack._update_runs(cur, cur.clone(), cur.clone(), ["M"] * 5)
+    assert calls == [("step", 5, 0)]
+    # update_mlm_text: one-piece words equal to a substituted question word follow it, every occurrence
+    task = mlm_task.build_mlm_task([(7001,)], [[(7001,)]], [True], [(2054,), (3609,), (7001,), (2054,)], [], "vlmo",
+                                   max_len=12)
+    tasks = [None, mlm_task.MlmTask(**vars(task))]
+    tasks[1].words_mlm = list(task.words_mlm)
+    ids = torch.zeros(2, 12, dtype=torch.long)
+    msk = torch.zeros(2, 12, dtype=torch.long)
+    BatchedVQAttack._write_mlm_row(ids, msk, 1, tasks[1])
+    before = ids[1].tolist()
+    assert before[:6] == [101, 2054, 3609, 103, 2054, 102] and msk[1].tolist()[:7] == [1] * 6 + [0]
+    changed = attack._follow_substitutions(tasks, [1], ids, msk, [[], [(1, 2054, 9999)]])
+    assert changed and ids[1].tolist()[:6] == [101, 9999, 3609, 103, 9999, 102]
+    assert not attack._follow_substitutions(tasks, [1], ids, msk, [[], []])
+    assert task.words_mlm[0] == (2054,)                                       # the caller's task is untouched
