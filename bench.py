@@ -60,7 +60,57 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=40,
                     help="PGD steps of the CPU sample (default: one full 40-step example, ~10-15 s on 16 cores)")
     ap.add_argument("--no-b256", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only, runs without a GPU: the ranks rendezvous over gloo on the host, gather "
+                         "stand-in success bits and rank 0 prints a line whose value is null (no measurement)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """``--gpus N`` (N > 1) without a launcher environment: start the N ranks as CHILD processes under
+    ``torch.distributed.run`` -- before this process has made any GPU call (it never makes one: a process that has
+    initialised HIP must not exec or fork GPU work on these hosts) -- let them inherit stdout / stderr (rank 0 prints
+    the JSON line) and return the launcher's exit code: a failed rank fails the whole run."""
+    import subprocess
+    if not args.dry_run and os.environ.get("VQA_DIST_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()               # counting devices does not initialise the runtime
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible; refusing to run fewer ranks under an "
+                             "N-GPU label".format(args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("--gpus {} without a launcher environment: starting {} ranks: {}".format(args.gpus, args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd)
+
+
+def dry_run(args, world, rank):
+    """The launch path without the GPU work: rendezvous (gloo, host tensors), shard, gather, one line from rank 0."""
+    from vqattack_amd.attack.asr import SuccessLedger, shard_indices
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    if int(os.environ.get("VQA_BENCH_FAIL_RANK", "-1")) == rank:
+        raise SystemExit("rank {} fails on request (VQA_BENCH_FAIL_RANK)".format(rank))
+    ledger = SuccessLedger(world, rank, "cpu", force_collective=dist.is_initialized())
+    mine = shard_indices(world * args.batch, rank, world)
+    ledger.record(torch.tensor([i % 3 == 0 for i in mine]), sample_ids=mine)
+    asr = ledger.all_gather_rate(world * args.batch)
+    if rank == 0:
+        print(json.dumps({"metric": "adversarial_vqa_examples_per_sec", "value": None, "unit": "examples/s",
+                          "n_gpus": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "attack_success_rate": asr,
+                          "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
+                                          "calls": ledger.collectives} if dist.is_initialized() else None)}),
+              flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def synthetic_questions(batch, length, n_body, seed, device):
@@ -396,8 +446,18 @@ def cpu_baseline(args, cfg):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                 # plain `python bench.py --gpus N`: never a silent 1-GPU run under an N-GPU label
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py --gpus {} was launched with WORLD_SIZE={}: the launcher's --nproc-per-node and --gpus "
+                         "must agree".format(args.gpus, os.environ["WORLD_SIZE"]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # any torchrun launch, also N = 1
     if not torch.cuda.is_available():
@@ -446,7 +506,7 @@ def main():
         else:
             res = attack.attack_batch(images, ids, masks, words)
         adv_answers = black.vqa_answer(res.adv_images, res.adv_text_ids, masks)
-        ledger.record(adv_answers != clean_answers)
+        ledger.record(adv_answers != clean_answers)     # sample ids default to this rank's interleaved shard
         return res
 
     def fence():
@@ -466,7 +526,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    asr = ledger.all_gather_rate()            # RCCL all-gather of the success bits (N > 1); inside the timed region
+    asr = ledger.all_gather_rate(world * args.batch * args.steps)   # RCCL all-gather of the success bits (N > 1); inside the timed region
     fence()
     dt = time.perf_counter() - t0
     timer.remove()
@@ -485,7 +545,7 @@ def main():
         total = world * args.batch * args.steps
         line = {
             "metric": "adversarial_vqa_examples_per_sec", "value": round(total / dt, 4), "unit": "examples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "n_gpus": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "{} VQAttack {} ({}): batch {} per GPU, {} PGD steps, {}x{} images, questions of "
                                    "{} real tokens ([CLS] + {} words + [SEP]) padded to {}{}, eps 0.125 step 0.01 L-inf "

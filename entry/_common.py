@@ -36,7 +36,8 @@ def finish(rank, world, result, out_json=None):
         print("sweep", json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in result.items()
                                    if k in ("n_local", "seconds", "examples_per_sec_local", "gradient_steps", "n_batches",
                                             "mean_batch", "collectives")}), flush=True)
-        if out_json:
+        if out_json:       # result["adv_text"] holds EVERY rank's samples (run_sweep gathers them): the complete output
+            os.makedirs(os.path.dirname(os.path.abspath(out_json)), exist_ok=True)
             with open(out_json, "w") as f:
                 json.dump(result["adv_text"], f)
     if dist.is_initialized():

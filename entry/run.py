@@ -6,6 +6,7 @@
 Named configs and ``key=value`` overrides are parsed like sacred's ``with`` clause; only the keys the attack reads are
 known (``vlmo/config.py:20-90,283-337``): image_size, max_text_len, per_gpu_batchsize, model arch, seed, test_only.
 """
+import os
 import sys
 
 from _common import finish, init_distributed
@@ -57,7 +58,8 @@ def main():
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],
                     max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"],
                     force_collective=dist.is_initialized())
-    finish(rank, world, res)
+    # adversarial images <qid>.pt and the adversarial-text json go to attack_dir (vlmo_module.py:166-167,2059-2062,2095-2097)
+    finish(rank, world, res, os.path.join(cfg["attack_dir"], "adv_txt.json") if cfg["attack_dir"] else None)
 
 
 if __name__ == "__main__":

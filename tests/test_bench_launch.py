@@ -1,0 +1,66 @@
+"""``bench.py --gpus N`` must run N ranks or fail -- never a silent 1-GPU run under an N-GPU label.
+
+The driver may start the scaling bench either under ``torch.distributed.run`` (WORLD_SIZE set) or as a plain
+``python bench.py --gpus N``; in the second case bench.py itself starts N ranks as children before any GPU call.  These
+tests run on the CPU with ``--dry-run`` (launch plumbing only: gloo rendezvous on host tensors, stand-in success bits,
+no measurement -- ``value`` is null); the GPU twins are tests/test_bench_multirank.py and test_rccl_single_rank.py.
+Reference hook of the sharding: ``DistributedSampler(test_dataset, shuffle=False)``,
+``VLMO_VQAttack/vlmo/datamodules/multitask_datamodule.py:54``.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+LAUNCHER_VARS = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VQA_BENCH_FAIL_RANK",
+                 "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")
+
+
+def _run(argv, **env):
+    e = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    e.update(OMP_NUM_THREADS="1", **env)
+    return subprocess.run([sys.executable, BENCH] + argv, env=e, capture_output=True, text=True, timeout=300)
+
+
+def _json_lines(text):
+    return [json.loads(ln) for ln in text.splitlines() if ln.startswith("{")]
+
+
+def test_gpus_2_without_launcher_env_runs_two_ranks():
+    p = _run(["--gpus", "2", "--dry-run", "--batch", "5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-2000:]                     # only rank 0 reports
+    rec = lines[0]
+    assert rec["n_gpus"] == 2 and rec["collective"]["world"] == 2 and rec["dry_run"] is True and rec["value"] is None
+    assert abs(rec["attack_success_rate"] - 4 / 10) < 1e-6       # ids 0..9 over both ranks, success iff id % 3 == 0
+
+
+def test_world_size_mismatch_exits_non_zero():
+    p = _run(["--gpus", "2", "--dry-run"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+             MASTER_PORT="29999")
+    assert p.returncode != 0 and not _json_lines(p.stdout)
+    assert "must agree" in p.stderr
+
+
+def test_a_failing_rank_fails_the_run():
+    p = _run(["--gpus", "2", "--dry-run"], VQA_BENCH_FAIL_RANK="1")
+    assert p.returncode != 0
+
+
+def test_gpus_1_stays_single_process():
+    p = _run(["--gpus", "1", "--dry-run", "--batch", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _json_lines(p.stdout)[0]
+    assert rec["n_gpus"] == 1 and rec["collective"] is None
+
+
+def test_more_ranks_than_gpus_is_refused_for_rccl():
+    """Without --dry-run the RCCL path needs one GPU per rank: on a box with fewer GPUs the launch is refused loudly."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    p = _run(["--gpus", "8", "--no-cpu-baseline"])
+    assert p.returncode != 0 and "only" in p.stderr and not _json_lines(p.stdout)

@@ -28,8 +28,9 @@ def _worker(rank, world, port, n_samples, out_dir):
         for chunk in (mine[:cut], mine[cut:]):
             if chunk:
                 ledger.record(torch.tensor([i % 3 == 0 for i in chunk]), sample_ids=chunk)
-        bits, ids = ledger.all_gather_bits()
-        rate = ledger.all_gather_rate()
+        bits, ids = ledger.all_gather_bits(n_samples)
+        rate = ledger.all_gather_rate(n_samples)
+        assert ledger.collectives == 2, "one all-gather per call: counts are computed, not exchanged"
         torch.save({"bits": bits, "ids": ids, "rate": rate, "running": ledger.running_rate()},
                    os.path.join(out_dir, "r{}.pt".format(rank)))
     finally:
@@ -100,21 +101,32 @@ class _FakeBlack:
         return ((t < 0) & ((-t) % 3 == 0)).long()
 
 
-def _sweep_worker(rank, world, port, n_samples, mixed, out_dir):
+def _sweep_worker(rank, world, port, n_samples, mixed, out_dir, batch=4):
     from vqattack_amd.attack.sweep import run_sweep
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fake = _FakeAttack()
-        res = run_sweep("vlmo", None, _FakeBlack(), None, n_samples=n_samples, batch=4, image_size=8, text_len=12,
+        res = run_sweep("vlmo", None, _FakeBlack(), None, n_samples=n_samples, batch=batch, image_size=8, text_len=12,
                         device="cpu", rank=rank, world=world, log_every=0, max_words=5, dual_every=3, mixed=mixed,
                         attack=fake)
         torch.save({"asr": res["asr"], "n_local": res["n_local"], "steps": res["gradient_steps"],
-                    "qids": sorted(map(int, res["adv_text"])), "calls": fake.calls},
+                    "adv_text": res["adv_text"], "calls": fake.calls, "collectives": res["collectives"]},
                    os.path.join(out_dir, "s{}.pt".format(rank)))
     finally:
         dist.destroy_process_group()
+
+
+def _check_gathered_text(adv_text, n_samples):
+    """The complete adversarial-text output (adv_attack.py:734-735): every qid, with the ids the (fake) attack produced."""
+    from vqattack_amd.attack.sweep import synthetic_questions
+    ids, _, _ = synthetic_questions(n_samples, 12, seed=0, max_words=5)
+    want = ids.clone()
+    want[:, 1] = -want[:, 1]
+    assert sorted(map(int, adv_text)) == list(range(n_samples))
+    assert all(adv_text[str(q)] == want[q].tolist() for q in range(n_samples))
 
 
 @pytest.mark.parametrize("mixed", [False, True])
@@ -126,10 +138,25 @@ def test_two_rank_sweep_shard_ledger_gather(tmp_path, n_samples, mixed):
     ids, _, att = synthetic_questions(n_samples, 12, seed=0, max_words=5)
     want_asr = float((ids[:, 1] % 3 == 0).float().mean())
     got = [torch.load(os.path.join(str(tmp_path), "s{}.pt".format(r))) for r in range(world)]
-    assert sorted(got[0]["qids"] + got[1]["qids"]) == list(range(n_samples))        # every sample attacked exactly once
-    assert got[0]["qids"] == list(range(0, n_samples, 2)) and got[1]["qids"] == list(range(1, n_samples, 2))
     for r in range(world):
+        _check_gathered_text(got[r]["adv_text"], n_samples)        # rank 0 (and every other rank) holds ALL samples' text
         assert abs(got[r]["asr"] - want_asr) < 1e-6                                 # same gathered rate on every rank
-        assert got[r]["n_local"] == len(got[r]["qids"])
+        assert got[r]["n_local"] == len(range(r, n_samples, world))
         assert max(got[r]["calls"]) <= 4 and sum(got[r]["calls"]) == got[r]["n_local"]   # ragged batches, none lost
+        assert got[r]["collectives"] == 2                                           # success bits + adversarial text
     assert got[0]["steps"] + got[1]["steps"] == int((40 + att.sum(dim=1)).sum())
+
+
+def test_eight_rank_sweep_of_5003_samples_gathers_bits_and_text(tmp_path):
+    """BASELINE configs[3]'s sharding at its real size (5k samples over 8 ranks, uneven shards: 5003 = 8 * 625 + 3) on
+    gloo with the stand-in attack: ASR over all samples and the complete adversarial-text output on rank 0."""
+    from vqattack_amd.attack.sweep import synthetic_questions
+    world, n_samples = 8, 5003
+    mp.spawn(_sweep_worker, args=(world, _free_port(), n_samples, True, str(tmp_path), 64), nprocs=world, join=True)
+    ids, _, att = synthetic_questions(n_samples, 12, seed=0, max_words=5)
+    want_asr = float((ids[:, 1] % 3 == 0).float().mean())
+    got = [torch.load(os.path.join(str(tmp_path), "s{}.pt".format(r))) for r in range(world)]
+    _check_gathered_text(got[0]["adv_text"], n_samples)
+    assert [g["n_local"] for g in got] == [626, 626, 626, 625, 625, 625, 625, 625]
+    assert all(abs(g["asr"] - want_asr) < 1e-6 for g in got)
+    assert sum(g["steps"] for g in got) == int((40 + att.sum(dim=1)).sum())

@@ -88,14 +88,14 @@ def test_bench_single_rank_over_rccl(tmp_path):
     assert rec["n_gpus"] == 1 and rec["steps"] == 2
     coll = rec["collective"]
     assert coll is not None and coll["backend"] == "nccl" and coll["world"] == 1
-    assert coll["tensor_device"].startswith("cuda") and coll["calls"] >= 2      # counts + bits, on device tensors
+    assert coll["tensor_device"].startswith("cuda") and coll["calls"] == 1      # ONE all-gather of the bits, on a device tensor
     assert rec["attack_success_rate"] is not None
 
 
 def test_entry_run_single_rank_over_rccl(tmp_path):
     out = str(tmp_path / "run.out")
     code = _run(_entry_rank, (_free_port(), out, ["with", "tiny", "n_samples=6", "per_gpu_batchsize=3", "dual_every=3",
-                                                   "mixed=True"]))
+                                                   "mixed=True", "attack_dir=" + str(tmp_path / "attack_dir_VLMO")]))
     text = open(out).read()
     assert code == 0, text[-2000:]
     lines = text.splitlines()
@@ -103,8 +103,10 @@ def test_entry_run_single_rank_over_rccl(tmp_path):
     assert len(acc) == 1 and acc[0].split()[2] == "6"
     info = [ln for ln in lines if ln.startswith("dist_backend")]
     assert len(info) == 1, text[-2000:]
+    adv = json.load(open(str(tmp_path / "attack_dir_VLMO" / "adv_txt.json")))      # vlmo_module.py:2095-2097
+    assert sorted(map(int, adv)) == list(range(6)) and all(len(v) == 8 for v in adv.values())
     parts = info[0].split()
-    assert parts[1] == "nccl" and parts[3] == "1" and int(parts[5]) >= 2
+    assert parts[1] == "nccl" and parts[3] == "1" and int(parts[5]) == 2       # success bits + adversarial text
 
 
 def test_entry_vqa_single_rank_over_rccl(tmp_path):

@@ -91,7 +91,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     if save_dir:
         from ..preprocess import AdvImageWriter
         writer = AdvImageWriter(save_dir, device)     # <qid>.pt, (1,3,H,W) fp32, like adv_attack.py:714
-    adv_text = {}
+    adv_rows, adv_qids = [], []
     steps = 0
     done = 0
     n_batches = 0
@@ -121,8 +121,8 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             steps += res.gradient_steps * (1 if key == -2 else len(qids))
             if key != -2:
                 assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget) * len(qids) // len(qids)
-            for q, row in zip(qids, res.adv_text_ids.cpu().tolist()):
-                adv_text[str(q)] = row
+            adv_rows.append(res.adv_text_ids[:, :text_len])        # stays on the device until the sweep's one gather
+            adv_qids += qids
             if writer is not None:
                 writer.write(res.adv_images, qids)
             done += len(qids)
@@ -136,7 +136,12 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    asr = ledger.all_gather_rate()
+    asr = ledger.all_gather_rate(n_samples)
+    # the sweep's second output: every sample's adversarial question on every rank (rank 0 writes the json the reference
+    # writes at the end, adv_attack.py:734-735 / vlmo_module.py:2095-2097) -- one small all-gather of (qid, ids) rows
+    rows = torch.cat(adv_rows) if adv_rows else torch.zeros(0, text_len, dtype=torch.int64, device=device)
+    all_q, all_rows = ledger.all_gather_rows(adv_qids, rows, n_samples)
+    adv_text = {str(q): row for q, row in zip(all_q.cpu().tolist(), all_rows.cpu().tolist())}
     return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,
                 examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text,
                 n_batches=n_batches, mean_batch=(len(mine) / n_batches if n_batches else 0.0),

@@ -305,12 +305,14 @@ class FrozenVlmo(nn.Module):
         return torch.tanh(self.pooler(states[:, 0]))
 
     @torch.no_grad()
-    def vqa_answer(self, image, text_ids, text_masks):
-        """Black-box prediction: argmax over the answer vocabulary (objectives.vqa_test_step_after_pgd, :812-829)."""
+    def vqa_answer(self, image, text_ids, text_masks, n_answers=None):
+        """Black-box prediction: argmax over the answer vocabulary (objectives.vqa_test_step_after_pgd, :812-829).
+        ``n_answers``: restrict the victim to the first ``n_answers`` classes (a question type with a closed answer set,
+        e.g. yes / no); None = the whole vocabulary."""
         if self.vqa_classifier is None:
             raise RuntimeError("this FrozenVlmo was built without a VQA head")
         _, states = self.encode(image, self.text_embeddings(text_ids), text_masks)
-        return self.vqa_classifier(self.pooled(states)).argmax(dim=-1)
+        return self.vqa_classifier(self.pooled(states))[:, :n_answers].argmax(dim=-1)
 
 
 class VlmoAttackAdapters:
