@@ -36,11 +36,16 @@ typedef void* vqa_stream_t; /* a hipStream_t (NULL = the legacy default stream) 
 /* further bits the kernels may OR into a *flag word */
 #define VQA_FLAG_RANGE 1      /* set by VQA_CHECK_RANGE */
 #define VQA_FLAG_BAD_LABEL 2  /* vqa_ce_rows: a label is neither ignore_index nor in [0, V) (torch device-asserts) */
+#define VQA_FLAG_DEGENERATE 4 /* optimize_linear self-check (A-ch/utils.py:101-104,110-116) would fail: norm=1 with a sample
+                                 whose max |grad| is 0 or NaN, norm=2 with a non-finite sum of squares */
 
 int vqa_abi_version(void);
 const char* vqa_error_string(int code);
 
-/* Process-wide tuning knobs of the streaming kernels (not part of the reference's interface):
+#ifdef VQA_TUNING
+/* NOT part of the shipped library: libvqattack_hip.so runs one launch shape per kernel, fixed at compile time.  A build
+ * with -DVQA_TUNING (`python -m vqattack_amd.build --tuning` -> lib/libvqattack_hip_tuning.so, used by tools/ only)
+ * compiles the alternatives the sweeps of DESIGN.md compare and exposes them as process-wide knobs:
  *   option 0: resident workgroups per CU the grid is capped at (1..64, default 8)
  *   option 1: non-temporal hints, bit0 = gradient/second-stream loads, bit1 = result stores, bit2 = first/third-stream
  *             loads, bit3 = result stores only when the result exceeds the 256 MB Infinity Cache (default 1|4|8 = 13)
@@ -55,6 +60,8 @@ const char* vqa_error_string(int code);
  *   option 8: non-temporal hints of the cosine-loss kernel, bit0 = loads of `a`, bit1 = gradient stores, bit2 = loads
  *             of the targets `b` (default 4) */
 int vqa_set_option(int option, int value);
+#endif
+
 
 /* ---------------------------------------------------------------- L-infinity image update (hot)
  * sign(g) follows torch.sign: sign(+-0) = 0, sign(NaN) = 0.  clamp propagates NaN like torch.clamp.
@@ -131,9 +138,12 @@ int vqa_l1_fgm(const float* x, const float* g, const float* amax, const float* t
  *   kind 0 (clip_eta, norm=2):        out = t * min(1, eps / sqrt(max(1e-12, stat[b])))           A-ch/utils.py:31-39
  *   kind 1 (optimize_linear, norm=2): out = eps * (t / sqrt(max(1e-12, stat[b])))                 A-ch/utils.py:106-107,127
  *   kind 2 (optimize_linear, norm=1): out = eps * (sign(t) * [|t| == stat[b]] / stat2[b])         A-ch/utils.py:88-101,127
+ * flag (nullable): kinds 1 and 2 OR VQA_FLAG_DEGENERATE into it when the reference's self-check assert of
+ * optimize_linear (A-ch/utils.py:101-104, :110-116: the result must have unit norm) would fire for a sample; the same bit
+ * is set by vqa_l2_fgm / vqa_l1_fgm when their flag pointer is given.  No host sync: the caller reads the word once.
  */
 int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, float* out, int batch,
-                         size_t n_per_sample, float eps, int kind, vqa_stream_t stream);
+                         size_t n_per_sample, float eps, int kind, int* flag, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- cross-modal loss reduction
  * Rows of D contiguous floats, addressed as row(o, i) = base + o*stride0 + i*stride1 (strides in ELEMENTS) for
@@ -198,13 +208,18 @@ int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate
  * 3-d labels and the autograd backward: A-ch/attacks/fast_gradient_method.py:131-142, V-ch/...:115-126.
  * A row whose K labels are all ignore_index -- every position but the [MASK]-ed answer pieces in the reference's
  * workload, ALBEF_attack/adv_attack.py:433-558 -- has zero loss and a zero gradient whatever its logits are: they are not
- * read and no exponential is evaluated; the row costs its zero gradient store.
- * Algorithmic bytes: 8*V per live row (read the logits once from HBM, write the gradient once), 4*V per dead row. */
+ * read and no exponential is evaluated; the row costs its zero gradient store -- or nothing at all:
+ * row_state (nullable, `rows` bytes, requires grad): for a caller that hands the SAME gradient buffer to every launch of an
+ * attack (zero-filled once, together with row_state, when it is allocated).  row_state[r] != 0 means "the buffer's row r
+ * holds a live gradient"; a live row writes its gradient and sets the byte, a dead row stores zeros only if the byte is
+ * set and clears it.  With the labels of an attack fixed, dead rows are never written after the allocation.
+ * Algorithmic bytes: 8*V per live row (read the logits once from HBM, write the gradient once); per dead row 4*V without
+ * row_state, 0 with it. */
 int vqa_ce_max_label_sets(void);
 long vqa_ce_scratch_floats(int K, long groups);
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
                 long ignore_index, long rows_per_group, float* scratch, float* grad, float* row_loss, float gscale,
-                float* loss_out, int accumulate, int* flag, vqa_stream_t stream);
+                float* loss_out, int accumulate, int* flag, unsigned char* row_state, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------- text side
  * dst[b, k, :] = src[b, idx[k], :]  for src (B, L, D), idx int64[K] with 0 <= idx[k] < L.

@@ -502,6 +502,88 @@ def test_mlm_cross_entropy_flags_out_of_range_labels():
     assert torch.isfinite(slot).all() and int(flag.item()) == 0
 
 
+def test_mlm_cross_entropy_dead_rows_are_not_stored_with_a_workspace():
+    """External dense ``model_fn`` (logits (B, L, V), labels ignore_index except at the [MASK]-ed answer pieces,
+    adv_attack.py:433-558) with the attack's workspace: the gradient buffer is zero-filled once, a byte per row remembers
+    which rows hold a live gradient, dead rows are never stored again.  The result must equal the workspace-free launch
+    on every call -- also when the label pattern CHANGES between calls (rows that were live turn dead and have to be
+    zeroed exactly once) and when the batch shrinks (prefix view of the same buffer)."""
+    ops = _ops()
+    r = np.random.RandomState(11)
+    b, l, v = 6, 10, 30522
+    logits = torch.from_numpy(r.standard_normal((b, l, v)).astype(np.float32)).to(DEV)
+
+    def labels_with(live):
+        lab = torch.full((1, b * l), -100, dtype=torch.long)
+        for row in live:
+            lab[0, row] = int(r.randint(0, v))
+        return lab.to(DEV)
+
+    ws = ops.Workspace()
+    slot, ref_slot = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    patterns = [[3, 14, 27, 41, 55], [3, 14, 27, 41, 55], [4, 14, 30], [], [0, 59], [4, 14, 30]]
+    for step, live in enumerate(patterns):
+        lab = labels_with(live)
+        want = ops.mlm_cross_entropy(logits, lab, ref_slot, accumulate=False, rows_per_sample=l)           # fresh buffer
+        got = ops.mlm_cross_entropy(logits, lab, slot, accumulate=False, rows_per_sample=l, ws=ws)
+        assert torch.equal(got, want), (step, live)
+        assert torch.equal(slot, ref_slot) or (torch.isnan(slot).all() and torch.isnan(ref_slot).all())
+        state = ws.get(("ce_row_state", v), (b * l,), torch.uint8, logits.device, zero=True)
+        assert sorted(torch.nonzero(state).flatten().tolist()) == sorted(live)
+        dead = [i for i in range(b * l) if i not in live]
+        assert float(got.reshape(b * l, v)[dead].abs().max()) == 0.0
+    # a shrunken batch (attack_mixed: finished samples leave the batch) takes a prefix view of the same buffers
+    lab = labels_with([2, 17])[:, :3 * l].contiguous()
+    want = ops.mlm_cross_entropy(logits[:3], lab, ref_slot, accumulate=False, rows_per_sample=l)
+    got = ops.mlm_cross_entropy(logits[:3], lab, slot, accumulate=False, rows_per_sample=l, ws=ws)
+    assert torch.equal(got, want) and got.data_ptr() == ws.get(("ce_grad", v), (1,), torch.float32, logits.device).data_ptr()
+
+
+def test_optimize_linear_self_checks_are_reported_not_dropped():
+    """The reference asserts inside optimize_linear that its result has unit norm (utils.py:101-104 L1, :110-116 L2).
+    The only inputs that trip it -- an all-zero or NaN L1 gradient, a non-finite L2 norm -- raise AssertionError here
+    too (flag bit VQA_FLAG_DEGENERATE, one host read), standalone and inside the FGM / PGD operators."""
+    from vqattack_amd import _hip, attacks, utils
+    ops = _ops()
+    g = torch.randn(3, 3, 8, 8, device=DEV)
+    for norm in (1, 2):
+        utils.optimize_linear(g, 0.5, norm)                          # healthy gradients: no assert
+    bad = g.clone()
+    bad[1] = 0.0
+    utils.optimize_linear(bad, 0.5, 2)                               # L2 of a zero gradient is fine (avoid_zero_div)
+    with pytest.raises(AssertionError):
+        utils.optimize_linear(bad, 0.5, 1)                           # L1: every entry ties at 0 with sign 0
+    nan = g.clone()
+    nan[2, 0, 0, 0] = float("nan")
+    inf = g.clone()
+    inf[0, 1, 2, 3] = float("inf")
+    for t, norm in ((nan, 1), (nan, 2), (inf, 2)):
+        with pytest.raises(AssertionError):
+            utils.optimize_linear(t, 0.5, norm)
+    utils.optimize_linear(inf, 0.5, 1)                               # one infinite entry: sign * 1 / 1, unit L1 norm
+    # the fused FGM updates report the same bit into the attack's flag word
+    x = torch.zeros_like(g)
+    flag = ops.new_flag(DEV)
+    ops.l2_fgm(x, g, 0.1, -1, 1, flag=flag)
+    ops.l1_fgm(x, g, 0.1, -1, 1, flag=flag)
+    assert int(flag.item()) == 0
+    ops.l1_fgm(x, bad, 0.1, -1, 1, flag=flag)
+    assert int(flag.item()) == _hip.VQA_FLAG_DEGENERATE
+    flag.zero_()
+    ops.l2_fgm(x, inf, 0.1, -1, 1, flag=flag, check_range=False)
+    assert int(flag.item()) == _hip.VQA_FLAG_DEGENERATE
+
+    # through the operator API: a model whose gradient is non-finite for one sample
+    def model_fn(img):
+        f = (img * torch.tensor([1.0, float("inf"), 1.0], device=DEV).view(3, 1, 1, 1)).reshape(3, 1, -1)
+        return [f, f * 2.0]
+
+    y = [torch.ones(3, 1, 3 * 8 * 8, device=DEV)]
+    with pytest.raises(AssertionError):
+        attacks.projected_gradient_descent(model_fn, x + 0.1, 0.5, 0.1, 2, 2, clip_min=-1, clip_max=1, y=y + y,
+                                           ori_x=x + 0.1, time=1, ls=1, sanity_checks=False, flavor="albef")
+
+
 @pytest.mark.parametrize("k", [1, 3])
 def test_mlm_cross_entropy_per_sample_normalisation(k):
     """rows_per_sample = L: the loss is the SUM over samples of the batch-1 reference loss (each sample's label sets

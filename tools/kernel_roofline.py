@@ -83,8 +83,9 @@ def copy_probes(x, x0, g, out, n):
 
 
 def linf_section(x, x0, g, eta, out, n):
-    for nt in (1, 3, 5, 7, 13):
-        assert _hip.lib().vqa_set_option(1, nt) == 0
+    for nt in (1, 3, 5, 7, 13):                 # knob sweeps need the tuning build (VQA_TUNING_LIB=1); skipped otherwise
+        if not _hip.set_option(1, nt):
+            break
         report("vqa_linf_step [nt mask {}: grad loads {}, stores {}, x/x0 loads {}]".format(
             nt, "nt" if nt & 1 else "plain", "nt" if nt & 2 else ("nt above 256 MB" if nt & 8 else "plain"),
             "nt" if nt & 4 else "plain"), 16 * n,
@@ -129,7 +130,8 @@ def cos_section(b):
     report("vqa_neg_cos_rows (loss+grad, D=768), partials only (no in-kernel fold)", 12 * rows * 768,
            timeit(lambda: ops.neg_cos_rows(a, t, None, accumulate=False, ws=ws)), "A/B: cost of the arrival counters")
     for per_cu, inflight in ((0, 1), (8, 2), (8, 1), (4, 2), (0, 2)):     # last = defaults
-        assert _hip.lib().vqa_set_option(6, per_cu) == 0 and _hip.lib().vqa_set_option(7, inflight) == 0
+        if not (_hip.set_option(6, per_cu) and _hip.set_option(7, inflight)):
+            break
         report("vqa_neg_cos_rows (loss+grad, D=768) [grid {}, {} row(s) in flight]".format(
             "resident" if per_cu == 0 else "{}/CU".format(per_cu), inflight), 12 * rows * 768,
             timeit(lambda: ops.neg_cos_rows(a, t, slot, accumulate=False, ws=ws)), "A/B knob sweep")
@@ -151,13 +153,15 @@ def cos_section(b):
            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
                   reps=10))
     for nt in (0, 5, 6, 7, 4):
-        assert _hip.lib().vqa_set_option(8, nt) == 0
+        if not _hip.set_option(8, nt):
+            break
         report("vqa_neg_cos_rows_multi ({} layers, D=768) [nt mask {}: a loads {}, grad stores {}, b loads {}]".format(
             n_layers, nt, "nt" if nt & 1 else "plain", "nt" if nt & 2 else "plain", "nt" if nt & 4 else "plain"),
             12 * rows * 768 * n_layers,
             timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B knob sweep")
     for per_cu, inflight in ((0, 1), (8, 2), (8, 1), (0, 2)):
-        assert _hip.lib().vqa_set_option(6, per_cu) == 0 and _hip.lib().vqa_set_option(7, inflight) == 0
+        if not (_hip.set_option(6, per_cu) and _hip.set_option(7, inflight)):
+            break
         report("vqa_neg_cos_rows_multi ({} layers, D=768) [grid {}, {} row(s) in flight]".format(
             n_layers, "resident" if per_cu == 0 else "{}/CU".format(per_cu), inflight), 12 * rows * 768 * n_layers,
             timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B knob sweep")
@@ -182,14 +186,17 @@ def ce_section(b):
     labels = torch.randint(0, 30522, (1, rows), device="cuda")
     labels3 = torch.randint(0, 30522, (3, rows), device="cuda")
     ws = ops.Workspace()
-    for variant, threads in ((2, 256), (2, 512), (3, 512)):
-        assert _hip.lib().vqa_set_option(4, threads) == 0 and _hip.lib().vqa_set_option(5, variant) == 0
+    tuning = _hip.set_option(4, 512)
+    for variant, threads in (((2, 256), (2, 512), (3, 512)) if tuning else ((2, 512),)):
+        if tuning:
+            _hip.set_option(4, threads), _hip.set_option(5, variant)
         tag = "{} threads, {} logits loads".format(threads, "nt" if variant == 3 else "plain")
         report("vqa_ce_rows (loss+grad, K=1) [{}]".format(tag), 8 * rows * 30522,
                timeit(lambda: ops.mlm_cross_entropy(logits, labels, slot, accumulate=False, ws=ws)))
         report("vqa_ce_rows (loss+grad, K=1) [{}], row losses only (no in-kernel fold)".format(tag), 8 * rows * 30522,
                timeit(lambda: ops.mlm_cross_entropy(logits, labels, None, accumulate=False, ws=ws)), "A/B")
-    assert _hip.lib().vqa_set_option(4, 512) == 0 and _hip.lib().vqa_set_option(5, 2) == 0      # defaults
+    if tuning:
+        _hip.set_option(4, 512), _hip.set_option(5, 2)      # defaults
     report("vqa_ce_rows (loss+grad, K=3)", 8 * rows * 30522,
            timeit(lambda: ops.mlm_cross_entropy(logits, labels3, slot, accumulate=False, ws=ws)))
     report("vqa_ce_rows (loss only, K=1)", 4 * rows * 30522,
@@ -202,10 +209,16 @@ def ce_section(b):
         for s in range(b):
             lab[0, s * 40 + 1:s * 40 + 1 + live_per_sample] = torch.randint(0, 30522, (live_per_sample,), device="cuda")
         live = int((lab != -100).sum())
-        report("vqa_ce_rows (loss+grad, K=1, dense {} x 30522, {:.1%} dead rows skipped in-kernel)".format(
+        report("vqa_ce_rows (loss+grad, K=1, dense {} x 30522, {:.1%} dead rows, fresh gradient buffer per call)".format(
             rows, 1 - live / rows), (8 * live + 4 * (rows - live)) * 30522,
-            timeit(lambda: ops.mlm_cross_entropy(logits, lab, slot, accumulate=False, ws=ws, rows_per_sample=40)),
-            "8 V bytes per live row + 4 V per dead row (zero gradient)")
+            timeit(lambda: ops.mlm_cross_entropy(logits, lab, slot, accumulate=False, ws=None, rows_per_sample=40)),
+            "no workspace: 8 V bytes per live row + 4 V per dead row (its zero gradient is stored); allocation included")
+        ws3 = ops.Workspace()
+        report("vqa_ce_rows (loss+grad, K=1, dense {} x 30522, {:.1%} dead rows, attack workspace + row_state)".format(
+            rows, 1 - live / rows), 8 * live * 30522,
+            timeit(lambda: ops.mlm_cross_entropy(logits, lab, slot, accumulate=False, ws=ws3, rows_per_sample=40)),
+            "the external dense model_fn case: gradient buffer kept across iterations, dead rows never stored")
+        del ws3
         # live-rows form: what the bundled adapters hand over -- only the live rows exist at all
         small = logits[:b * live_per_sample].contiguous().reshape(b, live_per_sample, 30522)
         lab_s = torch.randint(0, 30522, (1, b * live_per_sample), device="cuda")

@@ -31,9 +31,9 @@ def setup(batch):
 
 
 def set_knobs(bpc, nt, unroll, chunked):
-    lib = _hip.lib()
-    for opt, val in ((0, bpc), (1, nt), (2, unroll), (3, chunked)):
-        assert lib.vqa_set_option(opt, val) == 0
+    for opt, val in ((0, bpc), (1, nt), (2, unroll), (3, chunked)):     # needs the tuning build (VQA_TUNING_LIB=1)
+        if not _hip.set_option(opt, val):
+            raise SystemExit("the knob sweep needs `python -m vqattack_amd.build --tuning` and VQA_TUNING_LIB=1")
 
 
 def warm(x0, bufs, g, reps=20):

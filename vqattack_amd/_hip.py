@@ -12,12 +12,15 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvqattack_hip.so")
+# tools/ only: the -DVQA_TUNING build (launch-shape knobs + A/B kernel variants), selected with VQA_TUNING_LIB=1
+TUNING_LIB_PATH = os.path.join(_HERE, "lib", "libvqattack_hip_tuning.so")
 
 VQA_CLIP = 1
 VQA_CHECK_RANGE = 2
 VQA_FLAG_RANGE = 1        # bits of a flag word
 VQA_FLAG_BAD_LABEL = 2
-ABI_VERSION = 2
+VQA_FLAG_DEGENERATE = 4   # optimize_linear's self-check would fail (all-zero / NaN L1 gradient, non-finite L2 norm)
+ABI_VERSION = 3
 
 _c_float_p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -31,7 +34,6 @@ _p = ctypes.c_void_p
 SIGNATURES = {
     "vqa_abi_version": (_i, []),
     "vqa_error_string": (ctypes.c_char_p, [_i]),
-    "vqa_set_option": (_i, [_i, _i]),
     "vqa_linf_init": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p, _p]),
     "vqa_linf_fgm": (_i, [_p, _p, _p, _sz, _f, _f, _f, _u, _p, _p]),
     "vqa_linf_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _u, _p, _p]),
@@ -45,7 +47,7 @@ SIGNATURES = {
     "vqa_l2_fgm": (_i, [_p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p, _p]),
     "vqa_l2_project": (_i, [_p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p]),
     "vqa_l1_fgm": (_i, [_p, _p, _p, _p, _p, _i, _sz, _f, _f, _f, _u, _p, _p]),
-    "vqa_scale_per_sample": (_i, [_p, _p, _p, _p, _i, _sz, _f, _i, _p]),
+    "vqa_scale_per_sample": (_i, [_p, _p, _p, _p, _i, _sz, _f, _i, _p, _p]),
     "vqa_neg_cos_partials": (_i, []),
     "vqa_neg_cos_rows": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _i, _l, _l, _l, _l, _l, _l, _f, _f, _p, _i, _p]),
     "vqa_neg_cos_max_layers": (_i, []),
@@ -53,7 +55,7 @@ SIGNATURES = {
     "vqa_sum_partials": (_i, [_p, _i, _p, _i, _f, _p]),
     "vqa_ce_max_label_sets": (_i, []),
     "vqa_ce_scratch_floats": (_l, [_i, _l]),
-    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _l, _p, _p, _p, _f, _p, _i, _p, _p]),
+    "vqa_ce_rows": (_i, [_p, _l, _p, _i, _l, _i, _l, _l, _p, _p, _p, _f, _p, _i, _p, _p, _p]),
     "vqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_embed_tokens": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
@@ -74,8 +76,11 @@ class HipExtensionError(RuntimeError):
     pass
 
 
-def load_library(path=LIB_PATH):
+def load_library(path=None):
     """dlopen the kernel library and type its entry points.  Raises if it is absent (no fallback)."""
+    tuning = os.environ.get("VQA_TUNING_LIB", "") not in ("", "0")
+    if path is None:
+        path = TUNING_LIB_PATH if tuning else LIB_PATH
     if not os.path.exists(path):
         raise HipExtensionError(
             "HIP kernel library not found at {} -- build it with `python -m vqattack_amd.build` "
@@ -88,11 +93,18 @@ def load_library(path=LIB_PATH):
     if lib.vqa_abi_version() != ABI_VERSION:
         raise HipExtensionError("{} implements C ABI version {}, this package binds version {}: rebuild it with "
                                 "`python -m vqattack_amd.build --force`".format(path, lib.vqa_abi_version(), ABI_VERSION))
-    # development overrides of the tuning knobs: VQA_OPTIONS="1=3,0=8" -> vqa_set_option(1, 3); vqa_set_option(0, 8)
-    for item in filter(None, os.environ.get("VQA_OPTIONS", "").split(",")):
-        opt, val = item.split("=")
-        if lib.vqa_set_option(int(opt), int(val)) != 0:
-            raise HipExtensionError("bad VQA_OPTIONS entry '{}'".format(item))
+    # tools/ only: VQA_OPTIONS="1=3,0=8" -> vqa_set_option(1, 3); vqa_set_option(0, 8).  The shipped library has no
+    # knobs (one launch shape per kernel, fixed at compile time): the overrides need the tuning build
+    options = [item for item in os.environ.get("VQA_OPTIONS", "").split(",") if item]
+    if options:
+        if not hasattr(lib, "vqa_set_option"):
+            raise HipExtensionError("VQA_OPTIONS needs the tuning build: `python -m vqattack_amd.build --tuning` and "
+                                    "VQA_TUNING_LIB=1 ({} has no vqa_set_option)".format(path))
+        lib.vqa_set_option.restype, lib.vqa_set_option.argtypes = _i, [_i, _i]
+        for item in options:
+            opt, val = item.split("=")
+            if lib.vqa_set_option(int(opt), int(val)) != 0:
+                raise HipExtensionError("bad VQA_OPTIONS entry '{}'".format(item))
     return lib
 
 
@@ -103,6 +115,18 @@ def lib():
             if _lib is None:
                 _lib = load_library()
     return _lib
+
+
+def set_option(option, value):
+    """tools/ only: a launch-shape knob of the TUNING build (VQA_TUNING_LIB=1).  Returns False when the loaded library is
+    the shipped one, which has no knobs (one variant per kernel, fixed at compile time); raises on a bad value."""
+    handle = lib()
+    if not hasattr(handle, "vqa_set_option"):
+        return False
+    handle.vqa_set_option.restype, handle.vqa_set_option.argtypes = _i, [_i, _i]
+    if handle.vqa_set_option(int(option), int(value)) != 0:
+        raise HipExtensionError("vqa_set_option({}, {}) rejected".format(option, value))
+    return True
 
 
 def check(code, what):

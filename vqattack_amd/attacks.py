@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._hip import HipExtensionError
+from ._hip import VQA_FLAG_DEGENERATE, HipExtensionError
 from .features import LayerFeatures, layer_pairs
 
 ALBEF = "albef"
@@ -271,19 +271,33 @@ def _mixed_loss_and_grad(model_fn, leaves, model_in, y, flavor, slot, mlm_labels
 
 
 # ----------------------------------------------------------------------------------------- image updates
-def _fgm_update(x, grad, eps, norm, clip_min, clip_max, flag=None, out=None):
+def _fgm_update(x, grad, eps, norm, clip_min, clip_max, flag=None, out=None, check_range=True):
+    """``flag``: range violations of ``x`` (``check_range``) and, for the L2 / L1 updates, the degenerate-gradient bit
+    that stands for the self-check asserts of the reference's ``optimize_linear`` (utils.py:101-104, :110-116)."""
     if norm == np.inf:
-        return ops.linf_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
+        return ops.linf_fgm(x, grad, eps, clip_min, clip_max, flag=flag if check_range else None, out=out)
     if norm == 2:
-        return ops.l2_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
-    return ops.l1_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out)
+        return ops.l2_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out, check_range=check_range)
+    return ops.l1_fgm(x, grad, eps, clip_min, clip_max, flag=flag, out=out, check_range=check_range)
 
 
-def _fgm_then_project(x, grad, x0, eps_iter, eps, norm, clip_min, clip_max, out):
+def _fgm_then_project(x, grad, x0, eps_iter, eps, norm, clip_min, clip_max, out, flag=None):
     if norm == np.inf:
         return ops.linf_step(x, grad, x0, eps_iter, eps, clip_min, clip_max, out=out)
-    mid = ops.l2_fgm(x, grad, eps_iter, clip_min, clip_max)
+    mid = ops.l2_fgm(x, grad, eps_iter, clip_min, clip_max, flag=flag, check_range=False)
     return ops.l2_project(mid, x0, eps, clip_min, clip_max, out=out)
+
+
+def _check_flag(flag, norm, sanity_checks):
+    """The one host read of an operator call's flag word.  The degenerate-gradient bit is the reference's unconditional
+    ``assert`` inside ``optimize_linear`` (norm 1 / 2 only); range and label bits are ``sanity_checks`` material.
+    Returns True when no sanity bit is set."""
+    if flag is None or not (sanity_checks or norm != np.inf):
+        return True
+    bits = int(flag.item())
+    assert not bits & VQA_FLAG_DEGENERATE, \
+        "optimize_linear: the optimal perturbation does not have unit norm (all-zero or non-finite gradient)"
+    return (bits & ~VQA_FLAG_DEGENERATE) == 0
 
 
 def _grad_of(leaf):
@@ -303,15 +317,15 @@ def fast_gradient_method(model_fn, x, eps, norm, ori_x, clip_min=None, clip_max=
     if eps == 0:
         return x
     xin = _as_image(x)
-    flag = ops.new_flag(xin.device) if (sanity_checks and (clip_min is not None or clip_max is not None)) else None
+    check_range = sanity_checks and (clip_min is not None or clip_max is not None)
+    flag = ops.new_flag(xin.device) if (check_range or norm != np.inf) else None
     leaf = xin.detach().requires_grad_(True)           # shares storage with x: nothing is written in place
     loss_buf = torch.zeros(1, dtype=torch.float32, device=xin.device)
     _loss_and_grad(model_fn, [leaf], leaf, y, ls, flavor, targeted, _LossSlot(loss_buf, 0), bkp=bkp, bkp_y=bkp_y,
                    flag=flag, per_sample=per_sample)
     _two_sided(clip_min, clip_max)
-    adv = _fgm_update(xin, _grad_of(leaf), eps, norm, clip_min, clip_max, flag=flag)
-    if sanity_checks and flag is not None:
-        assert int(flag.item()) == 0, "input x is outside [clip_min, clip_max]"
+    adv = _fgm_update(xin, _grad_of(leaf), eps, norm, clip_min, clip_max, flag=flag, check_range=check_range)
+    assert _check_flag(flag, norm, sanity_checks), "input x is outside [clip_min, clip_max]"
     return adv, loss_buf[0]
 
 
@@ -326,16 +340,16 @@ def fast_gradient_method_vl(model_fn, x, eps, norm, ori_x, clip_min=None, clip_m
         return x
     img = _as_image(x[0], "x[0]")
     emb = _as_image(x[1], "x[1]")
-    flag = ops.new_flag(img.device) if (sanity_checks and (clip_min is not None or clip_max is not None)) else None
+    check_range = sanity_checks and (clip_min is not None or clip_max is not None)
+    flag = ops.new_flag(img.device) if (check_range or norm != np.inf) else None
     x[0] = img.detach().requires_grad_(True)
     x[1] = emb.detach().requires_grad_(True)
     loss_buf = torch.zeros(1, dtype=torch.float32, device=img.device)
     _loss_and_grad(model_fn, [x[0], x[1]], [x[0], x[1]], y, ls, flavor, targeted, _LossSlot(loss_buf, 0), vl=True)
     text_grad = ops.gather_rows(_grad_of(x[1]), text_emb_pick)
     _two_sided(clip_min, clip_max)
-    adv = _fgm_update(img, _grad_of(x[0]), eps, norm, clip_min, clip_max, flag=flag)
-    if sanity_checks and flag is not None:
-        assert int(flag.item()) == 0, "input x is outside [clip_min, clip_max]"
+    adv = _fgm_update(img, _grad_of(x[0]), eps, norm, clip_min, clip_max, flag=flag, check_range=check_range)
+    assert _check_flag(flag, norm, sanity_checks), "input x is outside [clip_min, clip_max]"
     return adv, text_grad
 
 
@@ -362,9 +376,8 @@ def _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks):
     ok = [eps_iter <= eps]
     if norm == np.inf and clip_min is not None:
         ok.append(eps + clip_min <= clip_max)
+    ok.append(_check_flag(flag, norm, sanity_checks))     # the only host read of the flag word
     if sanity_checks:
-        if flag is not None:
-            ok.append(int(flag.item()) == 0)     # the only host read of the flag word
         assert np.all(ok)
 
 
@@ -437,7 +450,8 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     loss_buf = torch.zeros(max(nb_iter, 1) * (2 if dual else 1), dtype=torch.float32, device=xin.device)
     n_loss = 0
     ws = ops.Workspace()       # loss-gradient / CE scratch buffers live for the whole call, not per iteration
-    bad_flag = flag if flag is not None else (ops.new_flag(xin.device) if (dual and sanity_checks) else None)
+    bad_flag = flag if flag is not None else (
+        ops.new_flag(xin.device) if ((dual and sanity_checks) or norm != np.inf) else None)
     if graph and nb_iter > 0:
         if dual or norm != np.inf:
             raise ValueError("graph=True supports the feature-loss (ls == 1) L-inf loop only")
@@ -452,7 +466,8 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
                            flag=bad_flag)
             n_loss += 1
             _two_sided(clip_min, clip_max)
-            adv = _fgm_then_project(adv, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])
+            adv = _fgm_then_project(adv, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur],
+                                    flag=bad_flag)
         else:
             if flavor == ALBEF:      # A :163,177-181 slices y; V :162,175 passes it whole
                 y_feat, y_mlm, extra = [y[1], y[2]], [y[0]], dict(bkp=model_fn[0], bkp_y=[y[1], y[2]])
@@ -463,12 +478,14 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
                            flag=bad_flag)
             n_loss += 1
             _two_sided(clip_min, clip_max)
-            mid = _fgm_update(adv, _grad_of(leaf), eps_iter, norm, clip_min, clip_max, out=buf[1 - cur])
+            mid = _fgm_update(adv, _grad_of(leaf), eps_iter, norm, clip_min, clip_max, out=buf[1 - cur], flag=bad_flag,
+                              check_range=False)
             leaf = mid.detach().requires_grad_(True)
             _loss_and_grad(model_fn[1], [leaf], leaf, y_mlm, 0, flavor, targeted, _LossSlot(loss_buf, n_loss), ws=ws,
                            flag=bad_flag, per_sample=per_sample, **extra)
             n_loss += 1
-            adv = _fgm_then_project(mid, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[cur])
+            adv = _fgm_then_project(mid, _grad_of(leaf), x0, eps_iter, eps, norm, clip_min, clip_max, buf[cur],
+                                    flag=bad_flag)
             cur = 1 - cur            # result sits in buf[cur] again after the flip below
         cur = 1 - cur
         del leaf
@@ -489,7 +506,7 @@ def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, cli
     img = _as_image(x[0], "x[0]")
     emb = _as_image(x[1], "x[1]")
     has_clip = clip_min is not None or clip_max is not None
-    flag = ops.new_flag(img.device) if has_clip else None
+    flag = ops.new_flag(img.device) if (has_clip or norm != np.inf) else None
     buf = [torch.empty_like(img), torch.empty_like(img)]
     adv = _start_point(img, norm, eps, clip_min, clip_max, time, rand_minmax, init_eta, flag, buf[0])
     cur = 0
@@ -510,7 +527,8 @@ def projected_gradient_descent_vl(model_fn, x, eps, eps_iter, nb_iter, norm, cli
                        _LossSlot(loss_buf, it), vl=True, ws=ws, flag=flag)
         text_grad = ops.gather_rows(_grad_of(leaf_txt), attack_mask)
         _two_sided(clip_min, clip_max)
-        adv = _fgm_then_project(adv, _grad_of(leaf_img), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur])
+        adv = _fgm_then_project(adv, _grad_of(leaf_img), x0, eps_iter, eps, norm, clip_min, clip_max, buf[1 - cur],
+                                flag=flag)
         cur = 1 - cur
         del leaf_img, leaf_txt
     _finish(flag, eps, eps_iter, norm, clip_min, clip_max, sanity_checks)

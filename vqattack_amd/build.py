@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip.so")
+# the same sources with -DVQA_TUNING: launch-shape knobs behind vqa_set_option() + the A/B kernel variants (tools/ only)
+TUNING_LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip_tuning.so")
 SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "ce.hip", "text.hip", "image.hip", "attn.hip"]
 # -ffp-contract=off: the reference's op chain rounds after every add/mul; keep it that way (bit-exact parity).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
@@ -25,20 +27,23 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP kernels of vqattack_amd cannot be built")
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
+def _stale(path=LIB_PATH):
+    if not os.path.exists(path):
         return True
-    built = os.path.getmtime(LIB_PATH)
+    built = os.path.getmtime(path)
     deps = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)]
     deps.append(os.path.join(HERE, "..", "include", "vqattack_hip.h"))
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB_PATH
+def build(force=False, verbose=False, tuning=False):
+    """``tuning=True`` builds ``libvqattack_hip_tuning.so`` (select it with VQA_TUNING_LIB=1) instead of the product."""
+    target = TUNING_LIB_PATH if tuning else LIB_PATH
+    if not force and not _stale(target):
+        return target
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    cmd = [_hipcc()] + FLAGS + (["-DVQA_TUNING"] if tuning else []) + \
+        [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,9 +51,9 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
     if verbose and proc.stderr.strip():
         print(proc.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

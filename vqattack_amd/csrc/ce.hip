@@ -11,8 +11,11 @@
 // exp is the hardware v_exp_f32 path (__expf, ~2 ulp); the tests state 1e-4 relative against torch.
 // A label that is neither ignore_index nor in [0, V) poisons the loss with NaN and ORs VQA_FLAG_BAD_LABEL into *flag
 // (torch device-asserts on such a label; it is never silently dropped).
-// Algorithmic bytes: 4*V read + 4*V written per live row (8*V), 4*V written per dead row (all labels ignore_index: zero
-// gradient, logits untouched), against ~6 full passes per label set for log_softmax + nll_loss + their autograd backward.
+// Algorithmic bytes: 4*V read + 4*V written per live row (8*V); a dead row (all labels ignore_index: zero gradient,
+// logits untouched) costs 4*V written -- or NOTHING when the caller keeps the gradient buffer across launches and passes
+// `row_state`: one byte per row that remembers whether the row's gradient in that buffer is non-zero, so a dead row is
+// zeroed only if an earlier launch left a live gradient there (in an attack the labels are fixed: never) -- against ~6
+// full passes per label set for log_softmax + nll_loss + their autograd backward.
 #include "common.hpp"
 
 extern "C" int vqa_sum_partials(const float* partial, int count, float* dst, int accumulate, float scale,
@@ -154,17 +157,21 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
                                                          const int64_t* __restrict__ labels, int K, long rows, int V,
                                                          long ignore_index, CeNorm norm,
                                                          float* __restrict__ grad, float* __restrict__ row_loss,
-                                                         float gscale, int* __restrict__ flag) {
+                                                         float gscale, int* __restrict__ flag,
+                                                         unsigned char* __restrict__ row_state) {
   __shared__ float lds_m[kWaves], lds_s[kWaves];
   const long r = blockIdx.x;
   if (row_is_dead(labels, K, rows, r, ignore_index)) {       // nothing to learn from this row: zero loss, zero gradient
     if (threadIdx.x == 0) row_loss[r] = 0.0f;
-    if (GRAD) {
+    if (GRAD && (!row_state || row_state[r])) {              // workgroup-uniform: the buffer holds a stale live gradient
       float* g = grad + r * static_cast<long>(V);
       for (int j = threadIdx.x; j < V; j += kBlock) g[j] = 0.0f;
+      __syncthreads();                                       // every thread has read row_state[r]
+      if (row_state && threadIdx.x == 0) row_state[r] = 0;
     }
     return;
   }
+  if (GRAD && row_state && threadIdx.x == 0) row_state[r] = 1;
   const float* x = logits + r * row_stride;
   const bool vec = ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   // ---- sweep 1: online softmax statistics
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(kBlock) void ce_rows_kernel(const float* __restrict
 // head, a 16-byte aligned body of float4 and a <= 3 element tail (8-byte accesses run at 0.54-0.70x the 16-byte rate
 // on this chip, MI355X_MICROARCH.md).  Lane t < head owns x[t]; lane 8 + t owns tail element t.
 constexpr int kRegFloats = 32768;     // capacity of one workgroup's registers: THREADS * QUADS * 4
-static int g_ce_threads = 512;        // vqa_set_option(4, 256 | 512 | 1024); 512 measured 2-3 % ahead of 256 (profiles/r02)
-static int g_ce_variant = 2;          // vqa_set_option(5, 2 | 3): 2 = size-aware non-temporal logits loads, 3 = always
+VQA_KNOB g_ce_threads = 512;        // option 4 (256 | 512 | 1024); 512 measured 2-3 % ahead of 256 (profiles/r02)
+VQA_KNOB g_ce_variant = 2;          // option 5 (2 | 3): 2 = size-aware non-temporal logits loads, 3 = always
 
 struct RowGeom {
   const f32x4* x4;      // aligned body
@@ -270,7 +277,7 @@ template <bool GRAD, int MAXK, int THREADS, int WGPC, bool NTL>
 __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels, int K, long rows, int V, long ignore_index,
     CeNorm norm, float* __restrict__ grad, float* __restrict__ row_loss, float gscale,
-    int* __restrict__ flag, CeFold fold) {
+    int* __restrict__ flag, CeFold fold, unsigned char* __restrict__ row_state) {
   constexpr int kQuads = kRegFloats / 4 / THREADS;
   constexpr int kWavesT = THREADS / kWave;
   __shared__ float lds[kWavesT];
@@ -278,7 +285,9 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
   const RowGeom cur = row_geom(logits, r, V);
   if (row_is_dead(labels, K, rows, r, ignore_index)) {       // workgroup-uniform: no logits load, no exp, zeros out
     if (threadIdx.x == 0) __hip_atomic_store(row_loss + r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (GRAD) {
+    // row_state given: the gradient buffer persists across launches and this row's slice is known to be zero unless an
+    // earlier launch wrote a live gradient there -> nothing is stored (workgroup-uniform branch)
+    if (GRAD && (!row_state || row_state[r])) {
       float* g = grad + r * static_cast<long>(V);
       const int edge = edge_index(cur, V);
       if (edge >= 0) g[edge] = 0.0f;
@@ -289,10 +298,13 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
         const int j = i * THREADS + threadIdx.x;
         if (j < cur.nquad) __builtin_nontemporal_store(zero, g4 + j);
       }
+      __syncthreads();                                       // every thread has read row_state[r]
+      if (row_state && threadIdx.x == 0) row_state[r] = 0;
     }
     fold_row_losses<THREADS>(fold, row_loss, rows);
     return;
   }
+  if (GRAD && row_state && threadIdx.x == 0) row_state[r] = 1;   // this launch leaves a live gradient in the row
   f32x4 v[kQuads];
 #pragma unroll
   for (int i = 0; i < kQuads; ++i) {
@@ -366,26 +378,26 @@ __global__ __launch_bounds__(THREADS, WGPC * THREADS / 256) void ce_rows_reg_ker
 template <bool GRAD, int MAXK, int THREADS>
 static void launch_reg(int variant, long rows, hipStream_t st, const float* logits, const int64_t* labels, int K, int V,
                        long ignore_index, const CeNorm& norm, float* grad, float* row_loss, float gscale,
-                       int* flag, const CeFold& fold) {
+                       int* flag, const CeFold& fold, unsigned char* row_state) {
   // logits are read exactly once: beyond twice the 256 MB Infinity Cache a non-temporal load is 5 % ahead (2.5 GB:
   // 474 vs 497 us), below it the plain load still finds part of the producer GEMM's output in the cache (625 MB: 119
   // vs 122 us) -- profiles/r02/kernel_roofline_nt_b{64,256}.jsonl.  variant 3 forces nt (A/B).
   const bool big = static_cast<size_t>(rows) * V * sizeof(float) > (512ull << 20);
   if (variant == 3 || big)
     ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2, true><<<static_cast<int>(rows), THREADS, 0, st>>>(
-        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
+        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold, row_state);
   else
     ce_rows_reg_kernel<GRAD, MAXK, THREADS, 2, false><<<static_cast<int>(rows), THREADS, 0, st>>>(
-        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
+        logits, labels, K, rows, V, ignore_index, norm, grad, row_loss, gscale, flag, fold, row_state);
 }
 
 template <int THREADS>
 static void launch_reg_k(bool want_grad, int variant, long rows, hipStream_t st, const float* logits,
                          const int64_t* labels, int K, int V, long ignore_index, const CeNorm& norm, float* grad,
-                         float* row_loss, float gscale, int* flag, const CeFold& fold) {
+                         float* row_loss, float gscale, int* flag, const CeFold& fold, unsigned char* row_state) {
 #define VQA_CE_GO(G, MK) \
   launch_reg<G, MK, THREADS>(variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, \
-                             flag, fold)
+                             flag, fold, row_state)
   if (want_grad) {
     if (K == 1) VQA_CE_GO(true, 1); else if (K <= 4) VQA_CE_GO(true, 4); else VQA_CE_GO(true, 8);
   } else {
@@ -407,6 +419,7 @@ long vqa_ce_scratch_floats(int K, long groups) {
   return kArriveWords + static_cast<long>(K) * groups;
 }
 
+#ifdef VQA_TUNING
 int vqa_ce_set_threads(int threads) {   // reached through vqa_set_option(4, threads)
   if (threads != 256 && threads != 512 && threads != 1024) return VQA_ERR_SHAPE;
   g_ce_threads = threads;
@@ -418,12 +431,14 @@ int vqa_ce_set_variant(int variant) {   // reached through vqa_set_option(5, var
   g_ce_variant = variant;
   return VQA_OK;
 }
+#endif  // VQA_TUNING
 
 int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int K, long rows, int V,
                 long ignore_index, long rows_per_group, float* scratch, float* grad, float* row_loss, float gscale,
-                float* loss_out, int accumulate, int* flag, vqa_stream_t stream) {
+                float* loss_out, int accumulate, int* flag, unsigned char* row_state, vqa_stream_t stream) {
   clear_stale_error();
   if (!logits || !labels || !scratch || !row_loss) return VQA_ERR_NULL;
+  if (row_state && !grad) return VQA_ERR_NULL;               // row_state describes the gradient buffer
   if (K < 1 || K > kCeMaxK || rows < 0 || V <= 0 || row_stride < V || rows_per_group < 0) return VQA_ERR_SHAPE;
   const long rpg = (rows_per_group == 0 || rows_per_group > rows) ? (rows > 0 ? rows : 1) : rows_per_group;
   const long groups = rows > 0 ? (rows + rpg - 1) / rpg : 1;
@@ -441,21 +456,23 @@ int vqa_ce_rows(const float* logits, long row_stride, const int64_t* labels, int
   if (reg_path) {
     const CeFold fold{counters, loss_out, accumulate, gscale};
     const bool g = grad != nullptr;
+#ifdef VQA_TUNING
     if (g_ce_threads == 256)
-      launch_reg_k<256>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
-    else if (g_ce_threads == 512)
-      launch_reg_k<512>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
+      launch_reg_k<256>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold, row_state);
+    else if (g_ce_threads == 1024)
+      launch_reg_k<1024>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold, row_state);
     else
-      launch_reg_k<1024>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold);
+#endif
+    launch_reg_k<512>(g, g_ce_variant, rows, st, logits, labels, K, V, ignore_index, norm, grad, row_loss, gscale, flag, fold, row_state);
     return launch_status();
   }
   const int grid = static_cast<int>(rows);
   if (grad)
     ce_rows_kernel<true, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index, norm,
-                                                           grad, row_loss, gscale, flag);
+                                                           grad, row_loss, gscale, flag, row_state);
   else
     ce_rows_kernel<false, kCeMaxK><<<grid, kBlock, 0, st>>>(logits, row_stride, labels, K, rows, V, ignore_index,
-                                                            norm, grad, row_loss, gscale, flag);
+                                                            norm, grad, row_loss, gscale, flag, nullptr);
   const int rc = launch_status();
   if (rc != VQA_OK || !loss_out) return rc;
   if (rows > 0x7fffffffL) return VQA_ERR_SHAPE;

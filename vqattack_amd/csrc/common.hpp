@@ -11,6 +11,15 @@ constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup, one per SIMD
 constexpr int kBlocksPerCu = 8;    // default grid cap of a grid-stride launch: 8 workgroups per compute unit (grid_cap())
 
+// Launch-shape constants of the kernels.  The shipped library runs ONE variant, fixed at compile time (chosen from the
+// sweeps recorded in DESIGN.md); a build with -DVQA_TUNING (tools/ only: `python -m vqattack_amd.build --tuning`) turns
+// the constants into process-wide knobs behind vqa_set_option() and also compiles the alternatives the sweeps compare.
+#ifdef VQA_TUNING
+#define VQA_KNOB static int
+#else
+#define VQA_KNOB [[maybe_unused]] constexpr int
+#endif
+
 // torch.sign: (g > 0) - (g < 0); sign(+-0) = 0 and sign(NaN) = 0.
 __device__ __forceinline__ float sign_torch(float g) {
   return (g > 0.0f ? 1.0f : 0.0f) - (g < 0.0f ? 1.0f : 0.0f);

@@ -11,16 +11,16 @@ namespace vqa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- tuning knobs (vqa_set_option), defaults chosen from the round-1 sweep recorded in DESIGN.md
-static int g_opt_blocks_per_cu = 8;   // option 0
+// ---- launch shape (VQA_KNOB: compile-time constants in the shipped library, see common.hpp)
+VQA_KNOB g_opt_blocks_per_cu = 8;   // option 0
 // option 1: bit0 = nt loads of the second stream (the gradient: read exactly once), bit1 = nt stores of the result,
 // bit2 = nt loads of the first and third stream (x, x0), bit3 = nt stores only when the result is larger than the
 // 256 MB Infinity Cache (a smaller result is re-read from the cache by the white box's next forward; a larger one
 // cannot stay resident anyway and the plain-store allocation only costs bandwidth: tools/stream_probe, +10 % at 1.8 GB)
-static int g_opt_nontemporal = 1 | 4 | 8;
+VQA_KNOB g_opt_nontemporal = 1 | 4 | 8;
 constexpr size_t kNtStoreBytes = 256ull << 20;
-static int g_opt_unroll = 4;          // option 2: 16-byte tiles in flight per lane and stream (2, 4 or 8)
-static int g_opt_chunked = 0;         // option 3: 0 = grid-stride tiles, 1 = one contiguous chunk per workgroup
+VQA_KNOB g_opt_unroll = 4;          // option 2: 16-byte tiles in flight per lane and stream (2, 4 or 8)
+VQA_KNOB g_opt_chunked = 0;         // option 3: 0 = grid-stride tiles, 1 = one contiguous chunk per workgroup
 
 struct StepParams {
   float eps_iter, eps, cmin, cmax;
@@ -156,14 +156,18 @@ __global__ __launch_bounds__(kBlock) void stream1_kernel(const float* s0,
 template <class Op, int U>
 static void launch_vec(int nt, int grid, hipStream_t st, const f32x4* a0, const f32x4* a1, const f32x4* a2, f32x4* o,
                        size_t n4, const StepParams& p, int* flag, size_t chunk) {
+  // shipped hint set: nt loads on every read stream (1 | 4), nt stores when the result exceeds the Infinity Cache (| 2),
+  // plain first stream for an in-place update (& ~4) -> {1, 3, 5, 7}
   switch (nt & 7) {
+#ifdef VQA_TUNING
     case 0: stream4_kernel<Op, U, 0><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
-    case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     case 2: stream4_kernel<Op, U, 2><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
-    case 3: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     case 4: stream4_kernel<Op, U, 4><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
-    case 5: stream4_kernel<Op, U, 5><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     case 6: stream4_kernel<Op, U, 6><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+#endif
+    case 1: stream4_kernel<Op, U, 1><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 3: stream4_kernel<Op, U, 3><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
+    case 5: stream4_kernel<Op, U, 5><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
     default: stream4_kernel<Op, U, 7><<<grid, kBlock, 0, st>>>(a0, a1, a2, o, n4, p, flag, chunk); break;
   }
 }
@@ -197,9 +201,12 @@ static int launch_stream(const float* s0, const float* s1, const float* s2, floa
     if ((g_opt_nontemporal & 8) && n * sizeof(float) > kNtStoreBytes) nt |= 2;
     nt &= NTMASK;
     if (s0 == out) nt &= ~4;        // in-place update: the first stream is about to be rewritten, keep it plain
+#ifdef VQA_TUNING
     if (TUNABLE && unroll == 2) launch_vec<Op, 2>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
     else if (TUNABLE && unroll == 8) launch_vec<Op, 8>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
-    else launch_vec<Op, 4>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
+    else
+#endif
+    launch_vec<Op, 4>(nt, grid, st, a0, a1, a2, o, n4, p, flag, chunk);
     done = n4 * 4;
   }
   if (done < n) {
@@ -215,6 +222,7 @@ using namespace vqa;
 
 extern "C" {
 
+#ifdef VQA_TUNING
 int vqa_ce_set_threads(int threads);   // ce.hip
 int vqa_ce_set_variant(int variant);   // ce.hip
 int vqa_loss_set_option(int which, int value);   // loss.hip
@@ -247,6 +255,7 @@ int vqa_set_option(int option, int value) {
       return VQA_ERR_SHAPE;
   }
 }
+#endif  // VQA_TUNING
 
 int vqa_linf_init(const float* x, const float* eta, float* out, size_t n, float eps, float cmin, float cmax,
                   unsigned mode, int* flag, vqa_stream_t stream) {

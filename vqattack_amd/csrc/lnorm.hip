@@ -264,7 +264,16 @@ __global__ __launch_bounds__(kBlock) void per_sample_kernel(const float* s0, con
          i += static_cast<size_t>(gridDim.x) * kBlock)
       out[base + i] = norm_apply<KIND>(p, s0[base + i], TWO ? s1[base + i] : 0.0f, st, st2, bad);
   }
-  if ((p.mode & VQA_CHECK_RANGE) && bad) atomicOr(flag, 1);
+  if ((p.mode & VQA_CHECK_RANGE) && bad) atomicOr(flag, VQA_FLAG_RANGE);
+  // The reference's optimize_linear asserts that its result has unit norm (A-ch/utils.py:101-104 for L1, :110-116 for
+  // L2) -- a host sync per call.  The assert can only fire when a sample's statistic is degenerate: L1: max|g| is 0 (all
+  // entries tie with sign 0) or NaN; L2: the sum of squares is inf or NaN.  Reported as a flag bit instead.
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    bool degenerate = false;
+    if (KIND == kL2Fgm || KIND == kOptLinL2) degenerate = !(st < INFINITY);
+    if (KIND == kL1Fgm || KIND == kOptLinL1) degenerate = !(st > 0.0f) || !(st2 >= 1.0f);
+    if (degenerate) atomicOr(flag, VQA_FLAG_DEGENERATE);
+  }
 }
 
 template <int KIND, bool TWO>
@@ -359,13 +368,13 @@ int vqa_l1_fgm(const float* x, const float* g, const float* amax, const float* t
 }
 
 int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, float* out, int batch,
-                         size_t n_per_sample, float eps, int kind, vqa_stream_t stream) {
+                         size_t n_per_sample, float eps, int kind, int* flag, vqa_stream_t stream) {
   clear_stale_error();
   NormParams p{eps, 0.0f, 0.0f, 0u};
   switch (kind) {
     case 0: return launch_per_sample<kClipEtaL2, false>(t, nullptr, stat, nullptr, out, batch, n_per_sample, p, nullptr, stream);
-    case 1: return launch_per_sample<kOptLinL2, false>(t, nullptr, stat, nullptr, out, batch, n_per_sample, p, nullptr, stream);
-    case 2: return launch_per_sample<kOptLinL1, false>(t, nullptr, stat, stat2, out, batch, n_per_sample, p, nullptr, stream);
+    case 1: return launch_per_sample<kOptLinL2, false>(t, nullptr, stat, nullptr, out, batch, n_per_sample, p, flag, stream);
+    case 2: return launch_per_sample<kOptLinL1, false>(t, nullptr, stat, stat2, out, batch, n_per_sample, p, flag, stream);
     default: return VQA_ERR_SHAPE;
   }
 }

@@ -234,9 +234,10 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __res
   if (threadIdx.x == 0) dst[0] = accumulate ? dst[0] + s : s;
 }
 
-static int g_loss_blocks_per_cu = 0;   // vqa_set_option(6, n): 0 = exactly the resident workgroups, n > 0 = n per CU
-static int g_loss_rows_in_flight = 2;  // vqa_set_option(7, 1 | 2)
-static int g_loss_nt = 4;              // vqa_set_option(8, mask): bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b
+// launch shape (VQA_KNOB: compile-time constants in the shipped library, see common.hpp)
+VQA_KNOB g_loss_blocks_per_cu = 0;   // option 6: 0 = exactly the resident workgroups, n > 0 = n per CU
+VQA_KNOB g_loss_rows_in_flight = 2;  // option 7: 1 | 2
+VQA_KNOB g_loss_nt = 4;              // option 8: bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b
 
 template <int NCH, bool GRAD, bool PIPE2, int NT>
 static int launch_cos_inst(hipStream_t st, const LayerTable& tab, float* partial, const Fold& fold, const uint8_t* mask,
@@ -264,6 +265,7 @@ template <int NCH>
 static int launch_cos(bool grad, hipStream_t st, const LayerTable& tab, float* partial, const Fold& fold,
                       const uint8_t* mask, const RowAddr& ra, int D, float gscale, float eps) {
 #define VQA_COS_GO(G, P, N) launch_cos_inst<NCH, G, P, N>(st, tab, partial, fold, mask, ra, D, gscale, eps)
+#ifdef VQA_TUNING
   if (!grad) return g_loss_rows_in_flight == 2 ? VQA_COS_GO(false, true, 4) : VQA_COS_GO(false, false, 4);
   if (g_loss_rows_in_flight != 2) return VQA_COS_GO(true, false, 4);
   switch (g_loss_nt) {          // A/B knob of the loss + gradient kernel (two rows in flight)
@@ -273,6 +275,9 @@ static int launch_cos(bool grad, hipStream_t st, const LayerTable& tab, float* p
     case 7: return VQA_COS_GO(true, true, 7);
     default: return VQA_COS_GO(true, true, 4);
   }
+#else       // shipped: two rows in flight per wave, non-temporal loads of the targets only
+  return grad ? VQA_COS_GO(true, true, 4) : VQA_COS_GO(false, true, 4);
+#endif
 #undef VQA_COS_GO
 }
 
@@ -322,6 +327,7 @@ extern "C" {
 
 int vqa_neg_cos_partials(void) { return kLossMaxBlocks + kArriveWords; }   // partials + the arrival counters
 
+#ifdef VQA_TUNING
 int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_option(6 | 7 | 8, value)
   if (which == 6) {
     if (value < 0 || value > 8) return VQA_ERR_SHAPE;
@@ -337,6 +343,7 @@ int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_o
   g_loss_rows_in_flight = value;
   return VQA_OK;
 }
+#endif  // VQA_TUNING
 
 int vqa_neg_cos_rows(const float* a, const float* b, float* ga, float* partial, const uint8_t* row_mask,
                      long mask_period, long rows0, long rows1, int D, long a_stride0, long a_stride1,

@@ -194,7 +194,9 @@ def absmax_ties_per_sample(g):
     return amax, ties
 
 
-def l2_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
+def l2_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None, check_range=True):
+    """``flag``: receives VQA_FLAG_DEGENERATE when a sample's gradient norm is not finite (the reference's self-check in
+    optimize_linear, utils.py:110-116) and, with ``check_range``, VQA_FLAG_RANGE for inputs outside the clip range."""
     dev_f32(x, "x"), dev_f32(g, "grad")
     if g.shape != x.shape:
         raise ValueError("shape mismatch")
@@ -202,7 +204,7 @@ def l2_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     out = _out_like(x, out)
     batch, n_per = _per_sample(x)
     mode, lo, hi = _clip_args(clip_min, clip_max)
-    if flag is not None and mode:
+    if flag is not None and mode and check_range:
         mode |= VQA_CHECK_RANGE
     if x.numel() == 0:
         return out
@@ -228,7 +230,8 @@ def l2_project(adv, x0, eps, clip_min, clip_max, out=None):
     return out
 
 
-def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
+def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None, check_range=True):
+    """``flag``: receives VQA_FLAG_DEGENERATE when a sample's largest |gradient| is 0 or NaN (utils.py:101-104)."""
     dev_f32(x, "x"), dev_f32(g, "grad")
     if g.shape != x.shape:
         raise ValueError("shape mismatch")
@@ -236,7 +239,7 @@ def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     out = _out_like(x, out)
     batch, n_per = _per_sample(x)
     mode, lo, hi = _clip_args(clip_min, clip_max)
-    if flag is not None and mode:
+    if flag is not None and mode and check_range:
         mode |= VQA_CHECK_RANGE
     if x.numel() == 0:
         return out
@@ -246,14 +249,16 @@ def l1_fgm(x, g, eps_iter, clip_min, clip_max, flag=None, out=None):
     return out
 
 
-def scale_per_sample(t, stat, stat2, eps, kind, out=None):
+def scale_per_sample(t, stat, stat2, eps, kind, out=None, flag=None):
+    """``flag`` (int32 device word): kinds 1 / 2 OR ``VQA_FLAG_DEGENERATE`` into it where the reference's unit-norm
+    self-check of ``optimize_linear`` would fail (utils.py:101-104, :110-116)."""
     dev_f32(t, "t"), dev_f32(stat, "stat")
     out = _out_like(t, out)
     batch, n_per = _per_sample(t)
     if t.numel() == 0:
         return out
     with _on(t):
-        check(lib().vqa_scale_per_sample(ptr(t), ptr(stat), ptr(stat2), ptr(out), batch, n_per, eps, kind,
+        check(lib().vqa_scale_per_sample(ptr(t), ptr(stat), ptr(stat2), ptr(out), batch, n_per, eps, kind, ptr(flag),
                                          stream_for(t)), "vqa_scale_per_sample")
     return out
 
@@ -285,15 +290,26 @@ class Workspace:
     def __init__(self):
         self._bufs = {}
 
-    def get(self, key, shape, dtype, device):
+    def get(self, key, shape, dtype, device, zero=False):
+        """A buffer per ROLE (``key``), not per shape: one flat allocation sized for the largest request so far, handed
+        out as a prefix view -- a driver whose active batch shrinks (``attack_mixed``: finished samples leave the batch)
+        keeps ONE set of buffers instead of one per batch size.  ``zero=True``: zero-filled when (re)allocated, and only
+        then; a smaller request of the same role sees the same leading rows."""
         if torch.cuda.is_current_stream_capturing():
-            return torch.empty(shape, dtype=dtype, device=device)
-        full = (key, tuple(shape), dtype, device)
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        numel = 1
+        for n in shape:
+            numel *= int(n)
+        full = (key, dtype, device)
         buf = self._bufs.get(full)
-        if buf is None:
-            buf = torch.empty(shape, dtype=dtype, device=device)
+        if buf is None or buf.numel() < numel:
+            buf = (torch.zeros if zero else torch.empty)(max(numel, 1), dtype=dtype, device=device)
             self._bufs[full] = buf
-        return buf
+        return buf[:numel].view(shape)
+
+    def persistent(self):
+        """True when a buffer handed out under a key is the SAME memory on the next request (not during graph capture)."""
+        return not torch.cuda.is_current_stream_capturing()
 
 
 def _scratch(ws, key, shape, dtype, device):
@@ -373,8 +389,11 @@ class SubWorkspace:
     def __init__(self, ws, tag):
         self.ws, self.tag = ws, tag
 
-    def get(self, key, shape, dtype, device):
-        return self.ws.get((self.tag, key), shape, dtype, device)
+    def get(self, key, shape, dtype, device, zero=False):
+        return self.ws.get((self.tag, key), shape, dtype, device, zero=zero)
+
+    def persistent(self):
+        return self.ws.persistent()
 
 
 def neg_cos_rows_multi(a_list, b_list, loss_out, accumulate, gscale=1.0, want_grad=True, row_weight=None,
@@ -446,7 +465,16 @@ def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want
     k = label_sets.shape[0]
     if k > lib().vqa_ce_max_label_sets():
         raise _hip.HipExtensionError("at most {} label sets per launch".format(lib().vqa_ce_max_label_sets()))
-    grad = _scratch(ws, "ce_grad", (rows, v), torch.float32, logits.device) if want_grad else None
+    # With a workspace the gradient buffer is the same memory in every iteration of the attack: it is zero-filled once
+    # and a byte per row remembers whether the row holds a live gradient, so the rows whose labels are all ignore_index
+    # (>= 90 % of a dense (B, L, V) logits tensor in the reference's workload) are never written again.
+    grad = row_state = None
+    if want_grad:
+        if ws is not None and ws.persistent() and rows > 0:
+            grad = ws.get(("ce_grad", v), (rows, v), torch.float32, logits.device, zero=True)
+            row_state = ws.get(("ce_row_state", v), (rows,), torch.uint8, logits.device, zero=True)
+        else:
+            grad = torch.empty((rows, v), dtype=torch.float32, device=logits.device)
     groups = 1 if rows_per_sample in (0, None) or rows == 0 else -(-rows // int(rows_per_sample))
     scratch = _scratch(ws, "ce_scratch", (max(int(lib().vqa_ce_scratch_floats(k, groups)), 1),), torch.float32,
                        logits.device)
@@ -454,8 +482,9 @@ def mlm_cross_entropy(logits, label_sets, loss_out, accumulate, gscale=1.0, want
     with _on(logits):
         check(lib().vqa_ce_rows(ptr(flat), flat.stride(0), ctypes.c_void_p(label_sets.data_ptr()), k, rows, v,
                                 ignore_index, int(rows_per_sample or 0), ptr(scratch), ptr(grad), ptr(row_loss), gscale,
-                                ptr(loss_out),
-                                1 if accumulate else 0, ptr(flag), stream_for(logits)), "vqa_ce_rows")
+                                ptr(loss_out), 1 if accumulate else 0, ptr(flag),
+                                None if row_state is None else ctypes.c_void_p(row_state.data_ptr()),
+                                stream_for(logits)), "vqa_ce_rows")
     return grad.reshape(logits.shape) if want_grad else None
 
 

@@ -1,16 +1,17 @@
 """``cleverhans.torch.utils`` of the reference, on the HIP kernels.
 
 Reference: ``ALBEF_VQAttack/cleverhans/cleverhans/torch/utils.py`` -- ``clip_eta`` :8-40, ``optimize_linear`` :70-128
-(the VLMO copy is arithmetically identical).  Same signatures, return values and exceptions.  Two deliberate
-differences, both host-sync removals: the reference's self-check ``assert``s inside ``optimize_linear`` (L1: unit
-L1 norm, L2: unit L2 norm; :101-104, :110-116) are not evaluated -- they can only fire on an all-zero (L1) or
-non-finite gradient and cost a device->host round trip per call.
+(the VLMO copy is arithmetically identical).  Same signatures, return values and exceptions, including the
+``AssertionError`` of the self-checks inside ``optimize_linear`` (L1: the result has unit L1 norm, L2: unit L2 norm;
+:101-104, :110-116): the kernels report the only inputs that can trip them -- an all-zero or NaN L1 gradient, a
+non-finite L2 norm -- as a flag bit (``VQA_FLAG_DEGENERATE``), read here once per call like the reference's own ``assert``
+does; inside the attack operators the same bit goes to the attack's flag word and is read once per PGD call.
 """
 import numpy as np
 import torch
 
 from . import ops
-from ._hip import dev_f32
+from ._hip import VQA_FLAG_DEGENERATE, dev_f32
 
 
 def _device_tensor(t, name):
@@ -39,13 +40,18 @@ def optimize_linear(grad, eps, norm=np.inf):
     """argmax_{|eta|_norm <= eps} <eta, grad>: eps*sign (inf), eps*grad/|grad|_2 (2), eps*sign*[|g|==max]/ties (1)."""
     if norm == np.inf:
         return ops.optimize_linear_linf(_device_tensor(grad, "grad"), eps)
-    if norm == 1:
+    if norm in (1, 2):
         g = _device_tensor(grad, "grad")
-        amax, ties = ops.absmax_ties_per_sample(g)
-        return ops.scale_per_sample(g, amax, ties, eps, kind=2)
-    if norm == 2:
-        g = _device_tensor(grad, "grad")
-        return ops.scale_per_sample(g, ops.sumsq_per_sample(g), None, eps, kind=1)
+        flag = ops.new_flag(g.device)
+        if norm == 1:
+            amax, ties = ops.absmax_ties_per_sample(g)
+            out = ops.scale_per_sample(g, amax, ties, eps, kind=2, flag=flag)
+        else:
+            out = ops.scale_per_sample(g, ops.sumsq_per_sample(g), None, eps, kind=1, flag=flag)
+        # the reference's `assert torch.all(opt_pert_norm == 1)` / `assert torch.allclose(...)`: one host read
+        assert not int(flag.item()) & VQA_FLAG_DEGENERATE, \
+            "optimize_linear: the optimal perturbation does not have unit norm (all-zero or non-finite gradient)"
+        return out
     raise NotImplementedError("Only L-inf, L1 and L2 norms are currently implemented.")
 
 
