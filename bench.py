@@ -113,15 +113,21 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
-def synthetic_questions(batch, length, n_body, seed, device):
-    """[CLS] + body ids U{1000..30521} + [SEP] + padding."""
+def synthetic_questions(batch, length, seed, device, min_words=4, max_words=12):
+    """[CLS] + n body ids U{1000..30521} + [SEP] + padding, n ~ U{min_words..max_words} per question, seeded
+    (n ~ U{4..12}).  Returns (ids, masks, words per question)."""
     g = torch.Generator().manual_seed(seed)
-    n_body = max(1, min(n_body, length - 2))
+    hi = max(1, min(max_words, length - 2))
+    lo = max(1, min(min_words, hi))
+    n = torch.randint(lo, hi + 1, (batch,), generator=g)
+    body = torch.randint(1000, 30522, (batch, hi), generator=g)
     ids = torch.zeros(batch, length, dtype=torch.long)
     ids[:, 0] = 101
-    ids[:, 1:1 + n_body] = torch.randint(1000, 30522, (batch, n_body), generator=g)
-    ids[:, 1 + n_body] = 102
-    return ids.to(device), (ids != 0).long().to(device)
+    for s in range(batch):
+        k = int(n[s])
+        ids[s, 1:1 + k] = body[s, :k]
+        ids[s, 1 + k] = 102
+    return ids.to(device), (ids != 0).long().to(device), n.tolist()
 
 
 def make_config(args):
@@ -148,34 +154,32 @@ def build_models(args, cfg, device):
     return "vlmo", white, black, VlmoAttackAdapters(white), cfg.max_text_len
 
 
-# HBM traffic per launch is NOT measured by this script (PMC counters need their own rocprofv3 passes): the tracked
-# summary below holds FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch for the kernels timed here
-# (tools/pmc_run.sh on the shipped build).  When a run's launch has the shape of a recorded phase, the recorded figure is
-# copied into the line as `traffic` with `traffic_kind: "recorded"`.
-PMC_SUMMARY = "profiles/r03/pmc_hot_kernels_summary.txt"
+# HBM traffic per launch is NOT measured by this script (PMC counters need their own rocprofv3 passes): the tracked JSON
+# below holds, per phase of tools/pmc_step.py, the launch SHAPE it ran and FETCH_SIZE x 2 (gfx950 correction) +
+# WRITE_SIZE per launch and kernel (tools/pmc_run.sh on the shipped build).  A figure is copied into the line -- as
+# `traffic` with `traffic_kind: "recorded"` -- only when the run's launch has exactly the recorded shape.
+PMC_TRAFFIC = "profiles/r04/pmc_traffic.json"
 
 
-def recorded_traffic(phase, kernel):
-    """HBM bytes per launch of `kernel` (substring of the kernel name) in phase `phase` of the tracked PMC summary."""
+def recorded_traffic(kernel, shape):
+    """(HBM bytes per launch, phase) of the record whose kernel name contains `kernel` and whose shape dict equals
+    `shape`; (None, None) when the tracked file has no such record."""
     try:
-        lines = open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()
-    except OSError:
-        return None
-    current = None
-    for ln in lines:
-        if ln.startswith("== phase"):
-            current = ln.split()[-1]
-        elif current == phase and kernel in ln and "HBM traffic" in ln:
-            return int(round(float(ln.split("HBM traffic")[1].split("MB")[0]) * 1e6))
-    return None
+        records = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
+    except (OSError, ValueError):
+        return None, None
+    for rec in records:
+        if kernel in rec.get("kernel", "") and rec.get("shape") == shape:
+            return int(rec["traffic_bytes"]), rec.get("phase")
+    return None, None
 
 
-def traffic_fields(phase, kernel, shape_note):
-    t = recorded_traffic(phase, kernel) if phase else None
+def traffic_fields(kernel, shape):
+    t, phase = recorded_traffic(kernel, shape) if shape else (None, None)
     if t is None:
-        return dict(traffic=None, traffic_source=PMC_SUMMARY)
-    return dict(traffic=t, traffic_kind="recorded", traffic_source="{} (phase {}: {})".format(PMC_SUMMARY, phase,
-                                                                                            shape_note))
+        return dict(traffic=None, traffic_source=PMC_TRAFFIC, traffic_shape=shape)
+    return dict(traffic=t, traffic_kind="recorded", traffic_shape=shape,
+                traffic_source="{} (phase {}: the same launch shape)".format(PMC_TRAFFIC, phase))
 
 
 class KernelTimer:
@@ -184,7 +188,7 @@ class KernelTimer:
 
     def __init__(self):
         self.step_events, self.step_numel = [], 0
-        self.loss_events, self.loss_rows = [], []
+        self.loss_events, self.loss_rows, self.loss_shape = [], [], None
         self._live = {}      # id(weight plane) -> (plane kept alive, device-side count of live rows): no host read here
 
     def install(self):
@@ -217,6 +221,7 @@ class KernelTimer:
                 live, per = timer._live[id(w)][1], rows // w.numel()
             timer.loss_rows.append((live if live is not None else rows, per,
                                     (12 if out is not None else 8) * a_.shape[-1] * len(a_list)))
+            timer.loss_shape = (tuple(a_.shape), len(a_list), w is not None)
             return out
         ops.linf_step, ops.neg_cos_rows_multi = timed_step, timed_loss
 
@@ -224,13 +229,22 @@ class KernelTimer:
         from vqattack_amd import ops
         ops.linf_step, ops.neg_cos_rows_multi = self._step, self._loss
 
+    def _loss_shape_record(self):
+        """Shape of the (single kind of) loss launch of this run, as tools/pmc_step.py records it; None when the run
+        launched more than one shape (ALBEF: text and image modality)."""
+        if self.loss_shape is None or len({(int(r), p, b) for r, p, b in self.loss_rows}) != 1:
+            return None
+        shape, maps, weighted = self.loss_shape
+        rows, per, _ = self.loss_rows[0]
+        return dict(op="neg_cos_rows_multi", maps=maps, batch=shape[0], tokens=shape[1], dim=shape[2],
+                    live_rows=int(rows) * per if weighted else int(rows))
+
     @staticmethod
     def _stats(events):
         ms = [a.elapsed_time(b) for a, b in events]
         return (sum(ms) / len(ms), min(ms), len(ms)) if ms else (None, None, 0)
 
-    def summary(self, step_phase=None, loss_phase=None):
-        """``step_phase`` / ``loss_phase``: phase of tools/pmc_step.py whose launch has this run's shape (or None)."""
+    def summary(self):
         torch.cuda.synchronize()
         mean_ms, min_ms, n = self._stats(self.step_events)
         if not n:
@@ -243,7 +257,7 @@ class KernelTimer:
                     algorithmic_bytes_per_launch=nbytes,
                     timing="hip events on the launch stream, per launch; HBM traffic is not measured in this run "
                            "(separate rocprofv3 --pmc passes, summary in traffic_source)",
-                    **traffic_fields(step_phase, "StepOp", "the same launch shape, back-to-back"))
+                    **traffic_fields("StepOp", dict(op="linf_step", elements=self.step_numel)))
         loss = None
         mean_ms, min_ms, n = self._stats(self.loss_events)
         if n:
@@ -255,11 +269,9 @@ class KernelTimer:
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
                         algorithmic_bytes_per_launch=round(total_bytes / n),
-                        note="12*D bytes per live row (read a, b; write grad); padded text rows are neither read nor "
-                             "counted",
-                        **traffic_fields(loss_phase, "neg_cos_rows_kernel",
-                                         "the same live rows in the untrimmed 617-token layout: the 30 padded text rows "
-                                         "per sample and map add their zero gradient rows, +76.7 MB"))
+                        note="12*D bytes per live row (read a, b; write grad); padded text rows (ragged questions inside "
+                             "the trimmed layout) are not read and cost their zero gradient row (4*D)",
+                        **traffic_fields("neg_cos_rows_kernel", self._loss_shape_record()))
         return step, loss
 
 
@@ -287,41 +299,53 @@ def step_kernel_microbench(batch, image_size, reps=40):
     return dict(kernel="vqa_linf_step", batch=batch, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), mean_launch_us=round(ms * 1e3, 2),
                 algorithmic_bytes_per_launch=nbytes, timing="{} back-to-back launches between two hip events".format(reps),
-                **traffic_fields({64: "step64", 256: "step256"}.get(batch) if image_size == 384 else None, "StepOp",
-                                 "the same launch"))
+                **traffic_fields("StepOp", dict(op="linf_step", elements=x.numel())))
 
 
-def copy_probe(nbytes=906 << 20, reps=10):
-    """What a plain device copy reaches on THIS box at a footprint beyond the 256 MB Infinity Cache (read + write =
-    2 x nbytes ~ the step kernel's 1.8 GB at batch 256): the platform's streaming rate, to be read next to the 8 TB/s
-    spec the fractions are priced against."""
-    src = torch.empty(nbytes // 4, device="cuda").normal_()
-    dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
+GUIDE_COPY_GBS = 6290.0     # float4 copy measured by MI355X_MICROARCH.md on this chip (the guide's "achievable" figure)
+
+
+def stream_probe(nbytes=452984832, reps=12):
+    """The platform's streaming rate on THIS box, from the best plain stream of tools/stream_probe.hip (built as
+    tools/libstream_probe.so): a 3-read-1-write stream and a copy at the step kernel's batch-256 footprint (453 MB per
+    buffer, 1.8 GB per launch -- beyond the 256 MB Infinity Cache), best of a few launch shapes each.  Reported next to
+    the 8 TB/s spec the fractions are priced against and the guide's measured float4 copy (6.29 TB/s)."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "libstream_probe.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared",
+                        os.path.join(ROOT, "tools", "stream_probe.hip"), "-o", path], check=True)
+    lib = ctypes.CDLL(path)
+    fn = lib.vqa_probe_stream
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_int, ctypes.c_size_t] + [ctypes.c_int] * 5
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    gbs = 2 * nbytes / (e0.elapsed_time(e1) / reps) / 1e6
-    return dict(kernel="torch.Tensor.copy_ (device to device)", footprint_bytes=2 * nbytes, achieved=round(gbs, 1),
-                unit="GB/s", frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
+    shapes = [(8, 4, 0), (8, 4, 1), (8, 4, 3), (16, 8, 3), (32, 4, 0), (16, 4, 1)]       # (workgroups per CU, unroll, nt)
+    out = {}
+    for name, op, streams in (("step_like_3r1w", 3, 4), ("copy_1r1w", 2, 2)):
+        best = max(((fn(op, nbytes, per_cu, unroll, nt, 0, reps), (per_cu, unroll, nt)) for per_cu, unroll, nt in shapes))
+        if best[0] < 0:
+            raise RuntimeError("stream probe failed with code {}".format(best[0]))
+        out[name] = dict(achieved=round(best[0], 1), unit="GB/s", frac_of_peak=round(best[0] / HBM_PEAK_GBS, 4),
+                         bytes_per_launch=nbytes * streams, workgroups_per_cu=best[1][0], unroll=best[1][1],
+                         nt_mask=best[1][2])
+    out["kernel"] = "tools/stream_probe.hip stream_kernel (plain float4 streams, best of {} launch shapes)".format(
+        len(shapes))
+    out["guide_float4_copy"] = dict(achieved=GUIDE_COPY_GBS, unit="GB/s", source="MI355X_MICROARCH.md")
+    return out
 
 
 def attention_traffic(batch, heads, seq, with_bias):
-    """Recorded HBM bytes of one forward + one backward call (phase `attn` of the tracked PMC summary: B=64, H=12,
-    S=587 with the shared bias slab -- the default bench shape), per kernel."""
-    if (batch, heads, seq, bool(with_bias)) != (64, 12, 587, True):
-        return dict(traffic=None, traffic_source=PMC_SUMMARY)
-    parts = {k: recorded_traffic("attn", k) for k in ("attn_fwd_kernel", "attn_delta_kernel", "attn_bwd_dkv_kernel",
-                                                      "attn_bwd_dq_from_ds_kernel")}
+    """Recorded HBM bytes of one forward + one backward call (the record of tools/pmc_step.py's `attn` phase with exactly
+    this shape), per kernel."""
+    shape = dict(op="attention", batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias))
+    parts = {k: recorded_traffic(k, shape)[0] for k in ("attn_fwd_kernel", "attn_delta_kernel", "attn_bwd_dkv_kernel",
+                                                        "attn_bwd_dq_from_ds_kernel")}
     if any(v is None for v in parts.values()):
-        return dict(traffic=None, traffic_source=PMC_SUMMARY)
-    return dict(traffic=sum(parts.values()), traffic_kind="recorded", traffic_per_kernel=parts,
-                traffic_source="{} (phase attn: the same four launches)".format(PMC_SUMMARY))
+        return dict(traffic=None, traffic_source=PMC_TRAFFIC, traffic_shape=shape)
+    return dict(traffic=sum(parts.values()), traffic_kind="recorded", traffic_per_kernel=parts, traffic_shape=shape,
+                traffic_source="{} (phase attn: the same four launches)".format(PMC_TRAFFIC))
 
 
 def attention_microbench(batch, heads, seq, with_bias, reps=10):
@@ -425,7 +449,7 @@ def cpu_baseline(args, cfg):
     log("cpu_baseline: {} threads, {} of {} PGD steps on 1 image".format(cores, args.cpu_baseline_steps,
                                                                          args.pgd_steps))
     model = FrozenVlmo(cfg, seed=0)
-    ids, masks = synthetic_questions(1, cfg.max_text_len, 8, seed=0, device="cpu")
+    ids, masks, _ = synthetic_questions(1, cfg.max_text_len, seed=0, device="cpu")
     g = torch.Generator().manual_seed(0)
     x0 = torch.empty(1, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
     ad = VlmoRefAdapters(model, ids, masks)
@@ -482,14 +506,16 @@ def main():
     cfg = make_config(args)
     flavor, white, black, adapters, text_len = build_models(args, cfg, device)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
-                             AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=False,
-                                          live_mlm_rows=not args.dense_mlm))
+                             AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=True,   # the reference's
+                                          live_mlm_rows=not args.dense_mlm))   # call sites use the default True (adv_attack.py:633-636)
     ledger = SuccessLedger(world, rank, coll_device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     images = torch.empty(args.batch, 3, cfg.image_size, cfg.image_size, device=device).uniform_(-1, 1, generator=gen)
-    n_body = max(args.joint, 8)
-    ids, masks = synthetic_questions(args.batch, text_len, n_body, seed=100 + rank, device=device)
+    # questions of n ~ U{4..12} words; a joint attack needs its --joint substitutable words
+    ids, masks, n_words = synthetic_questions(args.batch, text_len, seed=100 + rank, device=device,
+                                              min_words=max(4, args.joint), max_words=max(12, args.joint))
+    n_body = max(n_words)
     words = torch.zeros_like(ids, dtype=torch.bool)              # configs[1]: image-only 40-step PGD
     if args.joint:
         words[:, 1:1 + min(args.joint, text_len - 2)] = True     # configs[4]: joint image + text attack
@@ -534,10 +560,7 @@ def main():
         t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    full_shape = cfg.image_size == 384 and not args.joint and not args.dual
-    roof, roof_loss = timer.summary(
-        step_phase={64: "step64", 256: "step256"}.get(args.batch) if cfg.image_size == 384 else None,
-        loss_phase="cos13" if (full_shape and args.model == "vlmo_base" and args.batch == 64) else None)
+    roof, roof_loss = timer.summary()
     if rank == 0:
         log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 
@@ -548,18 +571,21 @@ def main():
             "n_gpus": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "{} VQAttack {} ({}): batch {} per GPU, {} PGD steps, {}x{} images, questions of "
-                                   "{} real tokens ([CLS] + {} words + [SEP]) padded to {}{}, eps 0.125 step 0.01 L-inf "
-                                   "clip [-1,1], random start, black-box scoring + ASR gather".format(
+                                   "{}..{} real tokens ([CLS] + n words + [SEP], n ~ U{{{}..{}}} seeded) padded to {}{}, "
+                                   "eps 0.125 step 0.01 L-inf clip [-1,1], random start, sanity_checks on, black-box "
+                                   "scoring + ASR gather".format(
                                        args.model, ("joint image+text attack ({} words)".format(args.joint)
                                                     if args.joint else "image PGD") +
                                        ((", dual loss (feature + MLM step per iteration, MLM head on {})".format(
                                            "all positions" if args.dense_mlm else "the live label rows"))
                                         if args.dual else ""), baseline_config(args), args.batch,
-                                       args.pgd_steps, cfg.image_size, cfg.image_size, n_body + 2, n_body, text_len,
+                                       args.pgd_steps, cfg.image_size, cfg.image_size, min(n_words) + 2, n_body + 2,
+                                       max(4, args.joint), max(12, args.joint), text_len,
                                        " (the all-padding columns are not run through the encoder)"
                                        if flavor == "vlmo" else ""),
                        "batch_per_gpu": args.batch, "pgd_steps": args.pgd_steps, "image_size": cfg.image_size,
-                       "text_len": text_len, "real_tokens": n_body + 2, "substitutable_words": args.joint,
+                       "text_len": text_len, "real_tokens": [min(n_words) + 2, n_body + 2],
+                       "mean_real_tokens": round(sum(n_words) / len(n_words) + 2, 2), "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
             "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
@@ -570,7 +596,7 @@ def main():
         }
         if not args.no_b256:
             try:
-                line["platform_copy_probe"] = copy_probe()
+                line["platform_stream_probe"] = stream_probe()
                 line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
             except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
                 line["roofline_b256"] = {"error": str(exc)[:200]}

@@ -315,6 +315,38 @@ int vqa_resize_bicubic_v_normalize(const uint8_t* src, int h_in, int w, int c, c
                                    const int32_t* bounds, int ksize, int h_out, float mean, float stdv, float* dst,
                                    vqa_stream_t stream);
 
+/* ---------------------------------------------------------------- white-box block glue (callee of the hot path)
+ * The frozen encoders' pre-LN transformer block -- reference: VLMO_VQAttack/vlmo/modules/multiway_transformer.py:184-201
+ * (x = x + gamma_1 * attn(norm1(x)); text tokens through norm2_text / mlp_text, image tokens through norm2_imag /
+ * mlp_imag, split at max_text_len :193-197; x = x + gamma_2 * mlp) and ALBEF's ViT block (ALBEF_attack/models/vit.py) --
+ * executed without an autograd graph by vqattack_amd/whitebox/_fused.py: library GEMMs + vqa_attn_* + these four entry
+ * points.  Rows are D contiguous floats (D % 4 == 0, D <= 1024), every pointer 16-byte aligned.
+ * Token layout for the modality split: a batch element has `period` rows (tokens), the first `split` are text tokens
+ * (segment 0), the rest image tokens (segment 1); a "split" tensor is two contiguous buffers, (B*split, D) and
+ * (B*(period-split), D) -- what the two expert GEMMs read and write.  period == 0: no split anywhere.
+ *
+ * vqa_ln_fwd: optional prologue  x_out = x + rscale * r  (r0 != NULL; r given whole as r0, or split as r0 / r1;
+ *   rscale NULL = 1), then  y = LayerNorm(x_out; gamma, beta, eps)  with (gamma1, beta1) for segment-1 rows when given,
+ *   y written whole (y1 == NULL) or split (y0 / y1); mean[row], rstd[row] saved for the backward.  Without a prologue
+ *   x_out is not written.  16 B/element with prologue, 8 without.  Replaces torch.addcmul + torch.cat + two slice copies
+ *   + F.layer_norm per stage (multiway_transformer.py:186-199).
+ * vqa_ln_bwd: dx = (g_a ? g_a : 0) + (g_inj ? g_inj : 0) + dLayerNorm/dx(dy; x, mean, rstd, gamma)  (frozen gamma/beta:
+ *   input gradient only); dy whole (dy1 == NULL) or split; g_a = gradient arriving over the residual path, g_inj = the
+ *   loss kernel's gradient of this feature map (vqa_neg_cos_rows_multi's ga[layer]); and, when dr0 != NULL,
+ *   dr = rscale * dx (rscale NULL = 1) written whole or split (dr1): the gradient of the branch the forward prologue
+ *   added.  20-28 B/element.  Replaces layer_norm's backward, the gradient-accumulation adds, addcmul's backward and the
+ *   slice / cat backward copies.
+ * vqa_gelu_fwd / vqa_gelu_bwd: a = gelu(h) / dh = da * gelu'(h), exact erf form (nn.GELU() of the reference's Mlp,
+ *   multiway_transformer.py:36-55); dh may alias da. */
+int vqa_ln_fwd(const float* x, const float* r0, const float* r1, const float* rscale, float* x_out,
+               const float* gamma0, const float* beta0, const float* gamma1, const float* beta1, float* y0, float* y1,
+               float* mean, float* rstd, long rows, int D, long period, long split, float eps, vqa_stream_t stream);
+int vqa_ln_bwd(const float* dy0, const float* dy1, const float* x, const float* mean, const float* rstd,
+               const float* gamma0, const float* gamma1, const float* g_a, const float* g_inj, const float* rscale,
+               float* dx, float* dr0, float* dr1, long rows, int D, long period, long split, vqa_stream_t stream);
+int vqa_gelu_fwd(const float* h, float* a, size_t n, vqa_stream_t stream);
+int vqa_gelu_bwd(const float* h, const float* da, float* dh, size_t n, vqa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

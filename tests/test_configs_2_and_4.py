@@ -1,0 +1,149 @@
+"""BASELINE.json configs[2] (ALBEF, batch 256, 40 steps) and configs[4] (VLMO-large joint attack, batch 128) at their FULL
+sizes in the driver-run GPU tests -- the thinnest part of the matrix after round 3 (ALBEF-base parity stopped at 8
+steps, and no tracked test launched the ALBEF loss at the batch-256 row count or the 25-map launch at batch 128).
+
+  * ALBEF-base, 384 px: the complete 40-step attack against the CPU oracle (reference-style batch-1 packing,
+    ``adv_attack.py:119-126``; loop ``projected_gradient_descent.py:130-152``), same tolerances as the VLMO twin;
+  * the loss launches of configs[2] at batch 256 -- image modality 13 x (256, 577, 768) = 5.9 GB per operand, text
+    modality 13 x (256, 40, 768) with row weights -- and of configs[4] at batch 128 -- 25 x (128, 617, 1024) = 8.1 GB per
+    operand -- through size-independent properties (the oracle would need hours): identity, orthogonality of the
+    gradient, weighted rows, the multi-map launch against per-map launches, bitwise reproducible fold;
+  * ``bench.py`` at the two configurations, a short budget, one well-formed line each.
+"""
+import copy
+import json
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def test_albef_base_full_40_step_attack_matches_cpu_oracle():
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import AlbefRefAdapters
+    from tests.test_fullsize_parity import EPS, EPS_ITER, _compare, _cpu_threads, _inputs
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_base
+    steps = 40
+    before = torch.get_num_threads()
+    torch.set_num_threads(_cpu_threads())
+    try:
+        cpu_model = FrozenAlbef(albef_base(384, mlm_probability=0.0), seed=0)
+        gpu_model = copy.deepcopy(cpu_model).to(DEV)
+        ids, masks, img, eta = _inputs([7], 9, seed=8)
+        attack = BatchedVQAttack(AlbefAttackAdapters(gpu_model), "albef", gpu_model.embedding_tables(),
+                                 AttackConfig(budget=steps, sanity_checks=True))
+        res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV),
+                                  torch.zeros_like(ids, dtype=torch.bool).to(DEV), init_eta=eta.to(DEV))
+        ad = AlbefRefAdapters(cpu_model, ids, masks)
+        tgt = ad.gen_ori_feats(img)
+        with torch.enable_grad():
+            adv, losses = oracle.projected_gradient_descent(
+                ad.pgd_attack, img, EPS, EPS_ITER, steps, np.inf, clip_min=-1, clip_max=1,
+                y=[tgt[0], tgt[1], None, None, None], ori_x=img, time=0, ls=1, flavor="albef", init_eta=eta)
+    finally:
+        torch.set_num_threads(before)
+    same = _compare(res.adv_images[0].cpu(), adv[0].detach(), steps, full_attack=True)
+    print("ALBEF-base 40 steps: {:.3%} of the pixels bit-identical to the CPU oracle".format(same))
+    assert len(res.loss_lists[0]) == steps
+    np.testing.assert_allclose(res.loss_lists[0], losses, rtol=1e-4)
+
+
+def _loss_launch_properties(n_maps, batch, tokens, dim, weights):
+    """One modality's loss launch at full size.  ``weights``: uint8 (batch, tokens) row weights or None."""
+    from vqattack_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(n_maps * 1000 + batch)
+    a = [torch.randn(batch, tokens, dim, device=DEV, generator=gen) for _ in range(n_maps)]
+    b = [torch.randn(batch, tokens, dim, device=DEV, generator=gen) for _ in range(n_maps)]
+    ws = ops.Workspace()
+    slot, slot2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    kw = dict(row_weight=weights, weight_period=batch) if weights is not None else {}
+    wsum = float(weights.sum()) if weights is not None else float(batch * tokens)
+    # (1) cos(a, a) = 1 on every live row: loss = -(sum of row weights) per map
+    ops.neg_cos_rows_multi(a, a, slot, accumulate=False, want_grad=False, **kw)
+    assert abs(float(slot) + n_maps * wsum) <= 2e-5 * n_maps * wsum
+    # (2) ONE launch over all maps == per-map launches: gradients bit for bit (rows are independent), loss to fp32 sum order
+    grads = ops.neg_cos_rows_multi(a, b, slot, accumulate=False, ws=ws, **kw)
+    total = 0.0
+    for k in (0, n_maps // 2, n_maps - 1):
+        g1 = ops.neg_cos_rows(a[k], b[k], slot2, accumulate=False, **kw)
+        assert torch.equal(g1, grads[k]), k
+        # the gradient of a cosine is orthogonal to its argument; weight-0 rows are exactly zero
+        assert float((g1 * a[k]).sum(-1).abs().max()) <= 2e-4
+        if weights is not None:
+            assert float(g1[weights == 0].abs().max()) == 0.0
+            two = (weights == 2).nonzero()
+            if two.numel():
+                s, t = two[0].tolist()
+                w1 = weights.clone()
+                w1[s, t] = 1
+                g_one = ops.neg_cos_rows(a[k], b[k], slot2, accumulate=False, row_weight=w1, weight_period=batch)
+                assert torch.equal(g1[s, t], 2.0 * g_one[s, t])
+        del g1
+    for k in range(n_maps):
+        ops.neg_cos_rows(a[k], b[k], slot2, accumulate=k > 0, want_grad=False, **kw)
+    total = float(slot2)
+    assert abs(float(slot) - total) <= 1e-5 * abs(total) + 1e-2
+    # (3) the in-kernel fold is reproducible bit for bit, launch after launch (no float atomics)
+    first = float(slot)
+    for _ in range(2):
+        ops.neg_cos_rows_multi(a, b, slot, accumulate=False, ws=ws, **kw)
+        assert float(slot) == first
+    # (4) antisymmetry in the target: -cos(a, -b) = +cos(a, b)
+    ops.neg_cos_rows_multi(a, [-t for t in b[:2]] + b[2:], slot2, accumulate=False, want_grad=False, **kw)
+    part = torch.zeros(1, device=DEV)
+    ops.neg_cos_rows_multi(a[:2], b[:2], part, accumulate=False, want_grad=False, **kw)
+    assert abs((float(slot2) + 2 * float(part)) - first) <= 1e-5 * abs(first) + 2e-2
+    del a, b, grads, ws
+    torch.cuda.empty_cache()
+
+
+def test_albef_loss_launches_at_batch_256():
+    """configs[2]: the two launches of one ALBEF feature-loss step at batch 256 -- image maps (13 x 256 x 577 x 768, no
+    weights) and text maps (13 x 256 x 40 x 768, padded tokens weigh 0: ``AlbefAttackAdapters.set_text``)."""
+    _loss_launch_properties(13, 256, 577, 768, None)
+    r = np.random.RandomState(4)
+    w = torch.zeros(256, 40, dtype=torch.uint8)
+    for s in range(256):
+        w[s, :2 + int(r.randint(4, 13))] = 1            # [CLS] + 4..12 words + [SEP]
+    _loss_launch_properties(13, 256, 40, 768, w.to(DEV))
+
+
+def test_vlmo_large_loss_launch_at_batch_128():
+    """configs[4]: 25 maps of (128, 617, 1024) in ONE launch (24.3 GB of operands + gradient), VLMo row weights: [CLS]
+    counts twice, padded text tokens not at all."""
+    r = np.random.RandomState(5)
+    w = torch.ones(128, 617, dtype=torch.uint8)
+    for s in range(128):
+        w[s, 2 + int(r.randint(4, 13)):40] = 0
+    w[:, 0] = 2
+    _loss_launch_properties(25, 128, 617, 1024, w.to(DEV))
+
+
+@pytest.mark.parametrize("argv,model", [
+    (["--model", "albef_base", "--batch", "256", "--pgd-steps", "2"], "albef_base"),
+    (["--model", "vlmo_large", "--joint", "8", "--batch", "128", "--pgd-steps", "9"], "vlmo_large"),
+], ids=["configs2-albef-b256", "configs4-vlmo-large-joint8-b128"])
+def test_bench_runs_the_two_configurations_at_full_batch(argv, model, capsys, monkeypatch):
+    """``python bench.py --model albef_base --batch 256`` / ``--model vlmo_large --joint 8 --batch 128`` with a short PGD
+    budget (the full 40 steps take minutes): one well-formed line, the step kernel timed at the full batch."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-b256"] + argv)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    batch = int(argv[argv.index("--batch") + 1])
+    assert rec["metric"] == "adversarial_vqa_examples_per_sec" and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["config"]["batch_per_gpu"] == batch and model in rec["config"]["workload"]
+    roof = rec["roofline"]
+    assert roof["algorithmic_bytes_per_launch"] == 16 * batch * 3 * 384 * 384 and 0 < roof["frac"] < 1
+    assert rec["roofline_loss"]["launches"] >= 2 and 0 < rec["roofline_loss"]["frac"] < 1
+    assert rec["roofline_attention"]["bound"] == "mfma"
+    torch.cuda.empty_cache()

@@ -1,0 +1,86 @@
+"""Attack-success bits at the model size BASELINE.json names, against the ORACLE pipeline's recorded outputs.
+
+``tests/golden/asr_base_<flavor>.json`` holds what the CPU oracle (``oracle/attack_loop`` per-sample loop with the full
+40-step budget + ``oracle/blackbox_ref`` per-question scorers; reference: ``adv_attack.py:559-733``,
+``vlmo_module.py:1892-2091``) produced in the build container for seeded samples at VLMO-base / ALBEF-base size, 384 px
+(``tests/golden/make_asr_fixture.py``: 200 / 64 samples, questions of 4..12 words with 0..4 substitutable words, every
+4th sample dual-loss): the victim's clean answers, its answers to the adversarial pairs, the substituted token ids and
+the success bits.  Here ONLY the product runs -- the batched joint attack on the MI355X (``attack_mixed``: HIP
+operators, mixed schedules and loss modes in one batch) and the batched black-box scorer -- on the same regenerated
+inputs, so no GPU time is spent waiting for the CPU.
+
+The victim answers from a closed answer set (``n_answers`` in the fixture) chosen so that the oracle's attack success
+rate lies inside 0.3 .. 0.7: with the full answer vocabulary the synthetic victim flips on every perturbed pair (round 3:
+ASR 1.0), and equal bits would say nothing.  Required (north_star: ASR within +-0.5 % of the reference's): clean answers
+equal, substituted ids equal, at most 0.5 % of the success bits differ (the number is printed); differing answer
+indices are reported with the oracle's decision margins.
+"""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import test_success_bits as tsb
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fixture(flavor):
+    path = os.path.join(ROOT, "tests", "golden", "asr_base_{}.json".format(flavor))
+    if not os.path.exists(path):
+        pytest.fail("missing fixture {} (python tests/golden/make_asr_fixture.py --flavor {})".format(path, flavor))
+    return json.load(open(path))
+
+
+@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
+def test_base_size_success_bits_match_the_recorded_oracle(flavor):
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    rec = _fixture(flavor)
+    assert rec["size"] == "base" and 0.3 <= rec["oracle_asr"] <= 0.7, "the fixture must be informative"
+    n, k = rec["n"], rec["n_answers"]
+    dev = torch.device("cuda", 0)
+    cfg_kw = dict(n_answers=k, k_test=min(128, k)) if flavor == "albef" else {}
+    white, black, adapters_cls, _, cfg = tsb.build(flavor, "base", **cfg_kw)
+    shape = rec["shape"]
+    ids, masks, att, tasks, _, images, eta = tsb.make_samples(flavor, cfg, n=n, seed=rec["seed"],
+                                                             words=tuple(shape["words"]), max_att=shape["max_att"],
+                                                             text_len=shape["text_len"])
+    proposals = [[(int(p), [int(v) for v in vs]) for p, vs in row] for row in rec["proposals"]]
+    white_gpu, black_gpu = copy.deepcopy(white).to(dev), copy.deepcopy(black).to(dev)
+    del white, black
+    sim = text_update.BagOfEmbeddingsSimilarity(seed=rec["sim_seed"])
+    attack = BatchedVQAttack(adapters_cls(white_gpu), flavor, white_gpu.embedding_tables(),
+                             AttackConfig(budget=rec["budget"], sanity_checks=True, sim_threshold=rec["sim_threshold"]),
+                             similarity_fn=sim)
+    answer = (lambda *a: black_gpu.vqa_answer(*a, n_answers=k)) if flavor == "vlmo" else black_gpu.vqa_answer
+    batch = 50 if flavor == "vlmo" else 32
+    got_clean, got_after, got_ids = [], [], []
+    for lo in range(0, n, batch):
+        sl = slice(lo, lo + batch)
+        img, tid, tm = images[sl].to(dev), ids[sl].to(dev), masks[sl].to(dev)
+        got_clean += answer(img, tid, tm).cpu().tolist()
+        res = attack.attack_mixed(img, tid, tm, att[sl].to(dev), init_eta=eta[sl].to(dev), proposals=proposals[sl],
+                                  tasks=tasks[sl])
+        got_after += answer(res.adv_images, res.adv_text_ids, tm).cpu().tolist()
+        got_ids.append(res.adv_text_ids.cpu())
+        del res, img
+    got_bits = [int(a != c) for a, c in zip(got_after, got_clean)]
+    want_bits, margins = rec["success_bits"], rec["adversarial_margins"]
+    differ = [s for s in range(n) if got_bits[s] != want_bits[s]]
+    ans_differ = [s for s in range(n) if got_after[s] != rec["adversarial_answers"][s]]
+    id_rows = int((torch.cat(got_ids) != torch.tensor(rec["adv_text_ids"])).any(dim=1).sum())
+    print("{} base: n = {}, closed answer set of {}, oracle ASR {:.4f}, product ASR {:.4f}; {} success bits differ "
+          "({:.2%}), {} adversarial answer indices differ, {} rows of substituted ids differ; oracle margins of the "
+          "differing samples: {}".format(flavor, n, k, float(np.mean(want_bits)), float(np.mean(got_bits)), len(differ),
+                                         len(differ) / n, len(ans_differ), id_rows,
+                                         [round(margins[s], 5) for s in sorted(set(differ + ans_differ))]))
+    assert got_clean == rec["clean_answers"], "the victim's clean answers differ"
+    assert id_rows == 0, "substituted token ids differ in {} samples".format(id_rows)
+    assert len(differ) <= 0.005 * n, "{} of {} success bits differ (> 0.5 %): samples {}".format(len(differ), n, differ)
+    assert abs(float(np.mean(got_bits)) - float(np.mean(want_bits))) <= 0.005
+    assert 0 < sum(got_bits) < n

@@ -1,6 +1,8 @@
 // Streaming-rate probe for MI355X (gfx950): what do plain read / write / copy / 3-read-1-write streams reach at the
 // footprints of the attack's kernels, and which launch shape gets there?  Stand-alone (no torch):
 //   hipcc -O3 --offload-arch=gfx950 tools/stream_probe.hip -o tools/stream_probe && tools/stream_probe
+// The same file builds as a shared library (-shared -fPIC -> tools/libstream_probe.so) whose one entry point,
+// vqa_probe_stream(), is what bench.py reports as the platform's streaming rate next to the kernels' fractions.
 // One JSON line per configuration: {"op", "MB" (bytes moved per launch), "grid", "unroll", "nt", "chunked", "us", "GBs"}.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -95,6 +97,51 @@ static void sweep(const char* name, const Bufs& B, size_t n4, int streams, int c
            name, mb, c.per_cu, c.unroll, c.nt, c.chunked ? 1 : 0, ms * 1e3, mb / ms);   // MB per ms = GB/s
     fflush(stdout);
   }
+}
+
+// One configuration, self-contained (allocates and frees its buffers): returns algorithmic GB/s (bytes per buffer x
+// streams / mean launch time over `reps` back-to-back launches), or a negative HIP error code.
+// op: 0 read, 1 write, 2 copy 1r:1w, 3 step-like 3r:1w, 4 loss-like 2r:1w.
+extern "C" double vqa_probe_stream(int op, size_t bytes, int per_cu, int unroll, int nt, int chunked, int reps) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess) return -1.0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (op < 0 || op > 4 || bytes < 16 || reps < 1 || per_cu < 1) return -2.0;
+  Bufs B{};
+  const int streams = op == 3 ? 4 : (op == 4 ? 3 : (op == 2 ? 2 : 1));
+  bool ok = hipMalloc(&B.a, bytes) == hipSuccess && hipMalloc(&B.out, bytes) == hipSuccess &&
+            hipMalloc(&B.sink, 64) == hipSuccess;
+  if (ok && op >= 3) ok = hipMalloc(&B.b, bytes) == hipSuccess;
+  if (ok && op == 3) ok = hipMalloc(&B.c, bytes) == hipSuccess;
+  double gbs = -3.0;
+  if (ok) {
+    (void)hipMemset(B.a, 0, bytes); (void)hipMemset(B.out, 0, bytes);
+    if (B.b) (void)hipMemset(B.b, 0, bytes);
+    if (B.c) (void)hipMemset(B.c, 0, bytes);
+    const size_t n4 = bytes / 16;
+    const int grid = cus * per_cu;
+    const bool ch = chunked != 0;
+    float ms = 0.f;
+#define GO3(OP, U) (nt == 0 ? run<OP, U, 0>(B, n4, grid, ch, reps) : nt == 1 ? run<OP, U, 1>(B, n4, grid, ch, reps) : \
+                    nt == 2 ? run<OP, U, 2>(B, n4, grid, ch, reps) : run<OP, U, 3>(B, n4, grid, ch, reps))
+#define GO2(OP) (unroll == 2 ? GO3(OP, 2) : unroll == 8 ? GO3(OP, 8) : GO3(OP, 4))
+    switch (op) {
+      case 0: ms = GO2(0); break;
+      case 1: ms = GO2(1); break;
+      case 2: ms = GO2(2); break;
+      case 3: ms = GO2(3); break;
+      default: ms = GO2(4); break;
+    }
+#undef GO2
+#undef GO3
+    gbs = static_cast<double>(bytes) * streams / 1e6 / ms;
+  }
+  if (B.a) (void)hipFree(B.a);
+  if (B.b) (void)hipFree(B.b);
+  if (B.c) (void)hipFree(B.c);
+  if (B.out) (void)hipFree(B.out);
+  if (B.sink) (void)hipFree(B.sink);
+  return gbs;
 }
 
 int main(int argc, char** argv) {

@@ -64,6 +64,10 @@ SIGNATURES = {
     "vqa_attn_scores_floats": (_l, [_i, _i, _i, _i]),
     "vqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p]),
     "vqa_attn_bwd_ws_floats": (_l, [_i, _i, _i, _i]),
+    "vqa_ln_fwd": (_i, [_p] * 13 + [_l, _i, _l, _l, _f, _p]),
+    "vqa_ln_bwd": (_i, [_p] * 13 + [_l, _i, _l, _l, _p]),
+    "vqa_gelu_fwd": (_i, [_p, _p, _sz, _p]),
+    "vqa_gelu_bwd": (_i, [_p, _p, _p, _sz, _p]),
     "vqa_resize_bicubic_h_u8": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "vqa_resize_bicubic_v_normalize": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p]),
 }

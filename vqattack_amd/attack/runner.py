@@ -49,8 +49,11 @@ class BatchResult:
     adv_images: torch.Tensor
     adv_text_ids: torch.Tensor
     loss_lists: list = field(default_factory=list)
-    substitutions: list = field(default_factory=list)   # per round: per sample [(position, old id, new id), ...]
-    gradient_steps: int = 0
+    substitutions: list = field(default_factory=list)   # per round: per sample (CALLER's order, one entry per sample of
+    #                                                      the batch) [(position, old id, new id), ...]
+    gradient_steps: int = 0      # attack_batch: steps of ONE sample (= white-box passes); attack_mixed: sum over samples
+    global_steps: int = 0        # white-box forward + backward passes the call ran (both drivers)
+    sample_steps: int = 0        # sum over the batch's samples of each sample's own gradient steps (both drivers)
     adv_text_ids_mlm: torch.Tensor = None               # dual-loss samples: the [MASK]-ed paraphrase after the attack
 
 
@@ -153,6 +156,17 @@ class BatchedVQAttack:
         if dual and mlm_labels is not None and tlen is not None and tlen < mlm_labels.shape[-1] and \
                 bool((mlm_labels[..., tlen:] != mlm_task.IGNORE).any()):
             raise ValueError("MLM labels beyond the batch's text length {} must be ignore_index".format(tlen))
+        try:
+            return self._attack_batch_body(images, text_ids, text_masks, attackable, mlm_logits_fn, dual, mlm_labels,
+                                           init_eta, proposals, tasks, mlm_ids, mlm_mask, blocks, adv, adv_ids, restore)
+        finally:                                 # also after an exception (OOM, bad label, HIP error): the adapters' MLM
+            if hasattr(a, "set_mlm_rows"):       # closure is dense again for any other caller
+                a.set_mlm_rows(None)
+
+    def _attack_batch_body(self, images, text_ids, text_masks, attackable, mlm_logits_fn, dual, mlm_labels, init_eta,
+                           proposals, tasks, mlm_ids, mlm_mask, blocks, adv, adv_ids, restore):
+        c, a = self.cfg, self.adapters
+        dev = images.device
         if hasattr(a, "set_mlm_rows"):
             # live-rows form of the MLM closure: the head runs, and the cross entropy is taken, at the label positions that
             # are targets only (the [MASK]-ed answer pieces, adv_attack.py:433-558) -- not over all B x L positions
@@ -213,10 +227,9 @@ class BatchedVQAttack:
                                 mlm_task.apply_substitutions(tasks[s].words_mlm, [(old, new) for (_, old, new) in per])
                                 ids_s = tasks[s].reencode()
                                 mlm_ids[s, :len(ids_s)] = torch.tensor(ids_s, device=dev, dtype=mlm_ids.dtype)
-        if hasattr(a, "set_mlm_rows"):
-            a.set_mlm_rows(None)                 # the adapters' MLM closure is dense again for any other caller
         res.substitutions = [text_update.substitution_lists(*r) for r in rounds]     # one host read, after the attack
         res.adv_images, res.adv_text_ids, res.adv_text_ids_mlm = restore(adv), adv_ids, mlm_ids
+        res.global_steps, res.sample_steps = res.gradient_steps, res.gradient_steps * images.shape[0]
         return res
 
     def _enter_layout(self, images, init_eta):
@@ -264,6 +277,17 @@ class BatchedVQAttack:
         weigh 0 and its MLM head is evaluated at its live label rows only; the fused image update is launched per run of
         consecutive samples of one kind.  The paraphrase follows the question's substitutions (``update_mlm_text``).
         """
+        a = self.adapters
+        try:
+            return self._attack_mixed_body(images, text_ids, text_masks, attackable, mlm_logits_fn, init_eta, proposals,
+                                           tasks)
+        finally:                                 # also after an exception: no live-rows / MLM-sample state may linger
+            if hasattr(a, "set_mlm_rows"):
+                a.set_mlm_rows(None)
+            if hasattr(a, "set_mlm_samples"):
+                a.set_mlm_samples(None)
+
+    def _attack_mixed_body(self, images, text_ids, text_masks, attackable, mlm_logits_fn, init_eta, proposals, tasks):
         c, a = self.cfg, self.adapters
         if c.norm != np.inf:
             raise ValueError("attack_mixed implements the L-inf attack")
@@ -359,13 +383,14 @@ class BatchedVQAttack:
                      for v in self._y_feature(targets)]
                 text_key = key
             leaf_img = cur[:n_act].detach().requires_grad_(True)
+            probing = [s for s in range(n_act) if kinds[s][t][1]] if masker is not None else []
             emb_t = adv_emb[:n_act]
-            if at_mlm:
-                emb_t = emb_t.clone()
-                emb_t[sel] = emb_mlm[sel]
+            if masker is None or probing:            # (a masked step without probing samples re-embeds every row below)
+                if at_mlm:
+                    emb_t = emb_t.clone()
+                    emb_t[sel] = emb_mlm[sel]
             if masker is not None:
                 emb_m = ops.embed_tokens(self.tables, masker(ids_step))   # one draw per step, like one per forward
-                probing = [s for s in range(n_act) if kinds[s][t][1]]
                 if probing:                                               # probe steps see the unmasked embeddings
                     idx = torch.tensor(probing, device=dev)
                     emb_m[idx] = emb_t[idx]
@@ -387,7 +412,7 @@ class BatchedVQAttack:
                 prev = adv_ids[:n_act].clone()
                 new_id, rank = text_update.accept_round(sub, scores, ori_ids[:n_act], adv_ids[:n_act],
                                                         self.similarity_fn, c.sim_threshold)   # in place, on the device
-                rounds.append((prev, new_id, rank))
+                rounds.append((prev, new_id, rank, n_act))
                 ops.embed_tokens(self.tables, adv_ids, out=adv_emb)
                 version += 1
                 text_cache.clear()
@@ -398,15 +423,19 @@ class BatchedVQAttack:
         if c.sanity_checks:
             bits = int(flag.item())
             assert bits == 0, "input images are outside [clip_min, clip_max]" if bits & 1 else "bad MLM label"
-        if hasattr(a, "set_mlm_rows"):
-            a.set_mlm_rows(None)
-            a.set_mlm_samples(None)
-        res.substitutions = [text_update.substitution_lists(*r) for r in rounds]
+        # rounds in the CALLER's sample order, one entry per sample of the batch (internally the batch is sorted by schedule
+        # length and a round covers the active prefix only)
+        for prev, new_id, rank, n_act in rounds:
+            per_round = [[] for _ in range(b)]
+            for i, per in enumerate(text_update.substitution_lists(prev, new_id, rank)):
+                per_round[order[i]] = per
+            res.substitutions.append(per_round)
         res.adv_images, res.adv_text_ids = restore(cur[inv]), adv_ids[inv][:, :text_len]
         if any_dual:
             res.adv_text_ids_mlm = mlm_ids[inv]
         res.loss_lists = [losses.tolist()]
-        res.gradient_steps = sum(total)
+        res.gradient_steps = res.sample_steps = sum(total)
+        res.global_steps = max(total)
         return res
 
     def _mixed_mlm_side(self, tasks, text_ids, text_masks, attackable):

@@ -118,9 +118,10 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
                 res = attack.attack_batch(images, tid, tmask, tatt)
             after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
             ledger.record(after != clean, sample_ids=qids)
-            steps += res.gradient_steps * (1 if key == -2 else len(qids))
+            # per-sample gradient steps, the same quantity on the bucketed and on the mixed path
+            steps += res.sample_steps or res.gradient_steps * (1 if key == -2 else len(qids))
             if key != -2:
-                assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget) * len(qids) // len(qids)
+                assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget)
             adv_rows.append(res.adv_text_ids[:, :text_len])        # stays on the device until the sweep's one gather
             adv_qids += qids
             if writer is not None:

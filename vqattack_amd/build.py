@@ -14,7 +14,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip.so")
 # the same sources with -DVQA_TUNING: launch-shape knobs behind vqa_set_option() + the A/B kernel variants (tools/ only)
 TUNING_LIB_PATH = os.path.join(LIB_DIR, "libvqattack_hip_tuning.so")
-SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "ce.hip", "text.hip", "image.hip", "attn.hip"]
+SOURCES = ["linf.hip", "lnorm.hip", "loss.hip", "ce.hip", "text.hip", "image.hip", "attn.hip", "block.hip"]
 # -ffp-contract=off: the reference's op chain rounds after every add/mul; keep it that way (bit-exact parity).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]

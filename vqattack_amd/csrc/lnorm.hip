@@ -128,7 +128,10 @@ __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict_
   const size_t base = static_cast<size_t>(blockIdx.y) * n_per;
   size_t lo, hi;
   chunk_bounds(n_per, chunks, lo, hi);
-  float run_max = 0.0f, run_cnt = 0.0f;   // |g| >= 0; NaN is ignored by fmaxf exactly as it never equals the max in the reference
+  // |g| >= 0.  fmaxf drops NaN; the reference's torch.max PROPAGATES it (the sample's maximum is NaN, nothing ties with
+  // it, the result is 0 / 0 and the self-check assert of optimize_linear fires, utils.py:96-104): a NaN anywhere in the
+  // chunk is tracked separately and makes the chunk's -- and so the sample's -- maximum NaN.
+  float run_max = 0.0f, run_cnt = 0.0f, seen_nan = 0.0f;
   if (VEC) {
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
     const size_t hi4 = hi / 4;
@@ -141,7 +144,10 @@ __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict_
         v[u] = (j < hi4) ? g4[j] : f32x4{-1.0f, -1.0f, -1.0f, -1.0f};      // fabsf(-1) never ties with a tile max of 0
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (j < hi4) m = fmaxf(m, fabsf(v[u][k]));
+          if (j < hi4) {
+            m = fmaxf(m, fabsf(v[u][k]));
+            seen_nan = (v[u][k] != v[u][k]) ? 1.0f : seen_nan;
+          }
       }
       const float tm = block_max(m, lds);
       float c = 0.0f;
@@ -159,12 +165,16 @@ __global__ __launch_bounds__(kBlock) void absmax_stage1(const float* __restrict_
     }
   } else {
     float m = 0.0f;
-    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) m = fmaxf(m, fabsf(g[base + i]));
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+      m = fmaxf(m, fabsf(g[base + i]));
+      seen_nan = (g[base + i] != g[base + i]) ? 1.0f : seen_nan;
+    }
     run_max = block_max(m, lds);
     float c = 0.0f;
     for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) c += (fabsf(g[base + i]) == run_max) ? 1.0f : 0.0f;
     run_cnt = block_sum(c, lds);
   }
+  if (block_max(seen_nan, lds) > 0.0f) run_max = __builtin_nanf("");
   if (threadIdx.x == 0) {
     const size_t slot = static_cast<size_t>(blockIdx.y) * chunks + blockIdx.x;
     ws[slot] = run_max;
@@ -177,9 +187,13 @@ __global__ __launch_bounds__(kBlock) void absmax_stage2(const float* __restrict_
   __shared__ float lds[kBlock / kWave];
   const float* pm = ws + static_cast<size_t>(blockIdx.x) * chunks;
   const float* pc = ws + static_cast<size_t>(batch) * chunks + static_cast<size_t>(blockIdx.x) * chunks;
-  float m = 0.0f;
-  for (int i = threadIdx.x; i < chunks; i += kBlock) m = fmaxf(m, pm[i]);
-  const float gm = block_max(m, lds);
+  float m = 0.0f, seen_nan = 0.0f;
+  for (int i = threadIdx.x; i < chunks; i += kBlock) {
+    m = fmaxf(m, pm[i]);
+    seen_nan = (pm[i] != pm[i]) ? 1.0f : seen_nan;
+  }
+  float gm = block_max(m, lds);
+  if (block_max(seen_nan, lds) > 0.0f) gm = __builtin_nanf("");       // torch.max propagates NaN
   float c = 0.0f;
   for (int i = threadIdx.x; i < chunks; i += kBlock) c += (pm[i] == gm) ? pc[i] : 0.0f;
   const float gc = block_sum(c, lds);

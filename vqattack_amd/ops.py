@@ -620,3 +620,48 @@ def greedy_accept(cand, scores, ori_ids, cur_ids, table, threshold):
                                       ctypes.c_void_p(rank.data_ptr()), ptr(table), table.shape[0], table.shape[1],
                                       float(threshold), stream_for(cur_ids)), "vqa_greedy_accept")
     return new_id, rank
+
+
+# ----------------------------------------------------------------------------------------- white-box block glue
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ln_fwd(x, gamma0, beta0, y0, mean, rstd, eps, r0=None, r1=None, rscale=None, x_out=None, gamma1=None, beta1=None,
+           y1=None, period=0, split=0):
+    """``vqa_ln_fwd`` on ``x`` (rows, D) fp32 contiguous: optional prologue ``x_out = x + rscale * r`` (r whole as ``r0`` or
+    split as ``r0`` / ``r1``), then LayerNorm with the second parameter set for segment-1 rows, output whole (``y0``) or
+    split (``y0`` / ``y1``).  Token layout: ``period`` rows per batch element, the first ``split`` are segment 0."""
+    rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    with _on(x):
+        check(lib().vqa_ln_fwd(_p(x), _p(r0), _p(r1), _p(rscale), _p(x_out), _p(gamma0), _p(beta0), _p(gamma1), _p(beta1),
+                               _p(y0), _p(y1), _p(mean), _p(rstd), rows, d, period, split, eps, stream_for(x)),
+              "vqa_ln_fwd")
+
+
+def ln_bwd(dy0, x, mean, rstd, gamma0, dx, dy1=None, gamma1=None, g_a=None, g_inj=None, rscale=None, dr0=None, dr1=None,
+           period=0, split=0):
+    """``vqa_ln_bwd``: ``dx = g_a + g_inj + LayerNorm'(dy)`` and optionally ``dr = rscale * dx`` (whole or split)."""
+    rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    with _on(x):
+        check(lib().vqa_ln_bwd(_p(dy0), _p(dy1), _p(x), _p(mean), _p(rstd), _p(gamma0), _p(gamma1), _p(g_a), _p(g_inj),
+                               _p(rscale), _p(dx), _p(dr0), _p(dr1), rows, d, period, split, stream_for(x)), "vqa_ln_bwd")
+
+
+def gelu_fwd(h, out=None):
+    dev_f32(h, "h")
+    out = torch.empty_like(h) if out is None else out
+    if h.numel():
+        with _on(h):
+            check(lib().vqa_gelu_fwd(_p(h), _p(out), h.numel(), stream_for(h)), "vqa_gelu_fwd")
+    return out
+
+
+def gelu_bwd(h, da, out=None):
+    """``out = da * gelu'(h)``; ``out=None`` overwrites ``da``."""
+    dev_f32(h, "h"), dev_f32(da, "da")
+    out = da if out is None else out
+    if h.numel():
+        with _on(h):
+            check(lib().vqa_gelu_bwd(_p(h), _p(da), _p(out), h.numel(), stream_for(h)), "vqa_gelu_bwd")
+    return out

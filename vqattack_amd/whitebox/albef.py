@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..features import LayerFeatures
+from . import _fused
 from ._mha import mha
 
 
@@ -161,6 +162,13 @@ class FrozenAlbef(nn.Module):
         self.eval()
         for p in self.parameters():
             p.requires_grad_(False)
+        # the ViT (577 of the <= 617 tokens of a pair) runs on whitebox/_fused.py on the GPU; see FrozenVlmo
+        self.fused_blocks = True
+        self._fused_spec = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._fused_spec = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _init(self, seed):
         g = torch.Generator().manual_seed(seed)
@@ -211,6 +219,11 @@ class FrozenAlbef(nn.Module):
         patches = image if image.dim() == 3 else \
             image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
         x = torch.cat([self.cls_token.expand(b, -1, -1), self.patch_proj(patches)], dim=1) + self.pos_embed
+        if self.fused_blocks and x.is_cuda and x.dtype == torch.float32 and _fused.supported(self.cfg.dim, self.cfg.heads):
+            if self._fused_spec is None:
+                self._fused_spec = _fused.vit_spec(self.vit_blocks, self.vit_norm, self.cfg.heads)
+            feats, states = _fused.encode(x, self._fused_spec, None, 0)
+            return states, feats
         feats = [x]
         for blk in self.vit_blocks:
             x = blk(x)
@@ -238,6 +251,17 @@ class FrozenAlbef(nn.Module):
         c = self.cfg
         if c.mlm_probability <= 0:
             return ids
+        if self._mask_gen is None and ids.is_cuda:
+            # production path: the draw happens on the device (no device -> host -> device round trip per white-box
+            # forward); seeded runs (parity tests against the CPU oracle) keep the host generator below
+            out = ids.clone()
+            p = torch.full(ids.shape, c.mlm_probability, device=ids.device)
+            sel = torch.bernoulli(p).bool() & (ids != c.pad_id) & (ids != c.cls_id)
+            rep = torch.bernoulli(torch.full_like(p, 0.8)).bool() & sel
+            out.masked_fill_(rep, c.mask_id)
+            rnd = torch.bernoulli(torch.full_like(p, 0.5)).bool() & sel & ~rep
+            words = torch.randint(c.vocab, ids.shape, device=ids.device, dtype=ids.dtype)
+            return torch.where(rnd, words, out)
         gen = None
         if self._mask_gen is not None:
             gen = torch.Generator().manual_seed(self._mask_gen)

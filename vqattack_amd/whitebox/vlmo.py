@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..features import LayerFeatures
+from . import _fused
 from ._mha import mha_packed
 
 
@@ -171,6 +172,15 @@ class FrozenVlmo(nn.Module):
         self.eval()
         for p in self.parameters():
             p.requires_grad_(False)
+        # On the GPU the block loop runs without an autograd graph inside (library GEMMs + csrc/attn.hip + the fused
+        # block glue of csrc/block.hip, whitebox/_fused.py) when the shapes are the hand-written kernels' (head size 64:
+        # every BASELINE configuration); False keeps the eager nn.Module loop (parity tests compare the two).
+        self.fused_blocks = True
+        self._fused_spec = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._fused_spec = None                  # .to(device): the spec holds device tensors of the frozen weights
+        return super()._apply(fn, *args, **kwargs)
 
     def _init(self, seed):
         g = torch.Generator().manual_seed(seed)
@@ -291,6 +301,10 @@ class FrozenVlmo(nn.Module):
         x = torch.cat([t, i], dim=1)
         if bias is None:
             bias = self.attention_bias(text_masks)
+        if self.fused_blocks and x.is_cuda and x.dtype == torch.float32 and _fused.supported(self.cfg.dim, self.cfg.heads):
+            if self._fused_spec is None:
+                self._fused_spec = _fused.vlmo_spec(self)
+            return _fused.encode(x, self._fused_spec, bias, n_text)
         feats = [x]
         for li, blk in enumerate(self.blocks):
             x = blk(x, bias[li], n_text)
