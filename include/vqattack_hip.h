@@ -276,10 +276,15 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
  * is masked, never used).  lse (B, H, Sq) receives log-sum-exp of the scores.
  * scores (nullable; vqa_attn_scores_floats(B, H, Sq, Sk) floats, 16-byte aligned): when given, the forward also stores
  * the pre-softmax scores scale * q k^T + bias -- a forward that will be differentiated hands them to vqa_attn_bwd, whose
- * key-block kernel then skips the q k^T product and the bias. */
+ * key-block kernel then skips the q k^T product and the bias.
+ * key_hole (nullable, int32 (B, 2)): keys [key_hole[2b], key_hole[2b+1]) of batch element b score -inf for every head
+ * and query -- the padded text tokens of a question shorter than the batch's text length (key padding of the reference's
+ * attention mask).  It lets a ragged batch share ONE (1, H, S, S) relative-position slab (batch stride 0) instead of a
+ * per-sample (B, H, S, S) bias.  The stored scores carry the -inf, so the scores-based backward needs nothing else; the
+ * score-recomputing forms of vqa_attn_bwd do not know the hole: callers that use them pass the padding inside `bias`. */
 int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
                  int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
-                 vqa_stream_t stream);
+                 const int* key_hole, vqa_stream_t stream);
 long vqa_attn_scores_floats(int B, int H, int Sq, int Sk);
 
 /* Gradients of the above w.r.t. q, k, v given go = d loss / d o (the bias is frozen: no gradient).  Deterministic (no

@@ -101,3 +101,42 @@ def test_packed_self_attention_gradient_and_determinism():
     assert torch.allclose(o, ref, atol=2e-5, rtol=1e-5)
     ref.backward(go)
     assert float((grads[0] - qkv.grad).abs().max()) <= 1e-4 * float(qkv.grad.abs().max())
+
+
+@pytest.mark.parametrize("b,h,s", [(3, 2, 77), (4, 12, 591), (2, 1, 40)])
+def test_key_hole_equals_the_dense_padding_mask(b, h, s):
+    """``KeyHoleBias``: one (1, H, S, S) slab shared by the batch + a per-sample masked key range [lo, hi) applied inside
+    the forward kernel -- against the same mask written into a per-sample dense bias, forward and backward, packed qkv;
+    holes inside the first key tile, across the first tile boundary, empty, and at the very end of the sequence."""
+    from vqattack_amd import attention
+    g = torch.Generator(device=DEV).manual_seed(s)
+    qkv = torch.randn(b, s, 3, h, 64, device=DEV, generator=g)
+    slab = torch.zeros(1, h, s, (s + 31) // 32 * 32, device=DEV)
+    slab[..., :s] = torch.randn(1, h, s, s, device=DEV, generator=g) * 0.5
+    slab = slab[..., :s]
+    holes = [[5, 14], [30, 37], [9, 9], [s - 3, s]][:b]
+    hole = torch.tensor(holes, dtype=torch.int32, device=DEV)
+    khb = attention.KeyHoleBias(slab.expand(b, -1, -1, -1), hole)
+    dense = khb.dense()
+    assert dense.shape == (b, h, s, s) and bool(torch.isinf(dense[0, 0, 0, 5:14]).all()) and bool(
+        torch.isfinite(dense[0, 0, 0, 14:]).all())
+    go = torch.randn(b, s, h, 64, device=DEV, generator=g)
+    a = qkv.clone().requires_grad_(True)
+    out_hole = attention.self_attention_packed(a, khb)
+    out_hole.backward(go)
+    c = qkv.clone().requires_grad_(True)
+    out_dense = attention.self_attention_packed(c, dense)
+    out_dense.backward(go)
+    assert torch.equal(out_hole, out_dense)                   # the same arithmetic: -inf enters the same accumulator
+    assert torch.equal(a.grad, c.grad)
+    ref_in = qkv.clone().requires_grad_(True)
+    ref = _sdpa(ref_in[:, :, 0], ref_in[:, :, 1], ref_in[:, :, 2], dense)
+    ref.backward(go)
+    assert torch.allclose(out_hole, ref, atol=2e-5, rtol=1e-5)
+    assert float((a.grad - ref_in.grad).abs().max()) <= 1e-4 * float(ref_in.grad.abs().max())
+    # masked keys receive no gradient
+    for i, (lo, hi) in enumerate(holes):
+        if hi > lo:
+            assert float(a.grad[i, lo:hi, 1:].abs().max()) == 0.0        # dK, dV rows of the hole
+    with torch.no_grad():                                      # forward-only path (targets, black-box scoring)
+        assert torch.equal(attention.self_attention_packed(qkv, khb), out_hole.detach())

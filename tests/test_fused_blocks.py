@@ -99,9 +99,15 @@ def test_gelu_kernels_match_torch(n):
     hr = h.clone().requires_grad_(True)
     want = F.gelu(hr)
     want.backward(da)
-    assert torch.allclose(ops.gelu_fwd(h), want.detach(), rtol=1e-6, atol=1e-7)
+    # erf is this kernel's own (packed-FMA minimax polynomials, < 1 ulp): it rounds differently from the library erff
+    # torch calls; in the left tail 1 + erf cancels, so the absolute error is ~ulp(1) * |x| / 2 on either side
+    assert torch.allclose(ops.gelu_fwd(h), want.detach(), rtol=2e-6, atol=1e-6)
     got = ops.gelu_bwd(h, da.clone())
-    assert torch.allclose(got, hr.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got, hr.grad, rtol=1e-5, atol=2e-6)
+    ref64 = F.gelu(h.double())                               # against fp64: the kernel is as accurate as torch's fp32
+    err_k = float((ops.gelu_fwd(h).double() - ref64).abs().max())
+    err_t = float((want.detach().double() - ref64).abs().max())
+    assert err_k <= max(2.0 * err_t, 1e-6), (err_k, err_t)
 
 
 def _vlmo_small():

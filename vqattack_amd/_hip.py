@@ -60,7 +60,7 @@ SIGNATURES = {
     "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_embed_tokens": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
     "vqa_greedy_accept": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
-    "vqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p]),
+    "vqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p]),
     "vqa_attn_scores_floats": (_l, [_i, _i, _i, _i]),
     "vqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p]),
     "vqa_attn_bwd_ws_floats": (_l, [_i, _i, _i, _i]),

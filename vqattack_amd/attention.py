@@ -79,38 +79,90 @@ def _longs(vals):
     return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
 
 
-def _forward(q, k, v, bias, bstr, scale, save_scores=False):
-    """Returns (o, lse, scores); ``scores`` is None unless ``save_scores`` and the buffer fits SCORES_LIMIT."""
+class KeyHoleBias:
+    """An additive attention mask in two parts: ``slab`` -- a bias broadcastable to (B, H, Sq, Sk), typically ONE
+    (1, H, S, S) relative-position slab shared by the batch -- and ``hole``, int32 (B, 2): keys ``[hole[b, 0], hole[b, 1])``
+    of sample b are masked for every head and query (the padded text tokens of a question shorter than the batch's text
+    length).  The forward kernel applies the hole itself (``key_hole`` of ``vqa_attn_fwd``), so a ragged batch does not
+    need a per-sample (B, H, S, S) copy of the slab; ``dense()`` is that copy, for consumers that want a plain tensor."""
+
+    def __init__(self, slab, hole):
+        self.slab, self.hole = slab, hole
+
+    def detach(self):
+        return self
+
+    def dense(self):
+        sk = self.slab.shape[-1]
+        b = self.hole.shape[0]
+        keys = torch.arange(sk, device=self.slab.device)
+        masked = (keys[None, :] >= self.hole[:, :1]) & (keys[None, :] < self.hole[:, 1:2])          # (B, Sk)
+        pad = torch.zeros(b, 1, 1, sk, device=self.slab.device).masked_fill(masked[:, None, None, :], float("-inf"))
+        return self.slab + pad
+
+
+def _split_hole(bias):
+    """(tensor bias or None, key hole or None) of a bias argument."""
+    if isinstance(bias, KeyHoleBias):
+        return bias.slab, bias.hole
+    return bias, None
+
+
+def _forward(q, k, v, bias, bstr, scale, save_scores=False, key_hole=None):
+    """Returns (o, lse, scores); ``scores`` is None unless ``save_scores`` and the buffer fits SCORES_LIMIT.
+    ``key_hole``: int32 (B, 2) device tensor, see ``KeyHoleBias``."""
     b, sq, h, _ = q.shape
     sk = k.shape[1]
     o = torch.empty((b, sq, h, HEAD_DIM), dtype=torch.float32, device=q.device)
     lse = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
     scores = None
     if save_scores:
-        n = int(lib().vqa_attn_scores_floats(b, h, sq, sk))
-        if 0 < 4 * n <= SCORES_LIMIT and 0 < 4 * int(lib().vqa_attn_bwd_ws_floats(b, h, sq, sk)) <= DS_WORKSPACE_LIMIT:
-            scores = torch.empty(n, dtype=torch.float32, device=q.device)
+        if scores_fit(b, h, sq, sk):
+            scores = torch.empty(int(lib().vqa_attn_scores_floats(b, h, sq, sk)), dtype=torch.float32, device=q.device)
+        elif key_hole is not None:
+            raise _hip.HipExtensionError("a key hole needs the saved-scores backward (the recomputing forms read the "
+                                         "padding from the bias): pass KeyHoleBias.dense() at this size")
     strides = _longs([q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                       v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
+    if key_hole is not None and (key_hole.dtype != torch.int32 or tuple(key_hole.shape) != (b, 2) or
+                                 not key_hole.is_cuda or not key_hole.is_contiguous()):
+        raise TypeError("key_hole must be a contiguous int32 (B, 2) HIP tensor")
     with torch.cuda.device(q.device):
         check(lib().vqa_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(lse), ptr(scores), b, h, sq, sk, strides,
-                                 _longs(bstr) if bstr else None, scale, stream_for(q)), "vqa_attn_fwd")
+                                 _longs(bstr) if bstr else None, scale,
+                                 None if key_hole is None else ctypes.c_void_p(key_hole.data_ptr()), stream_for(q)),
+              "vqa_attn_fwd")
     return o, lse, scores
 
 
-def _prepare(q, k, v, bias, scale):
+def scores_fit(b, h, sq, sk):
+    """True when a differentiated forward of this shape saves its scores (and the backward gets its dS workspace)."""
+    n = int(lib().vqa_attn_scores_floats(b, h, sq, sk))
+    return 0 < 4 * n <= SCORES_LIMIT and 0 < 4 * int(lib().vqa_attn_bwd_ws_floats(b, h, sq, sk)) <= DS_WORKSPACE_LIMIT
+
+
+def _prepare(q, k, v, bias, scale, need_grad=False):
+    """Returns (q, k, v, bias tensor, bias strides, scale, key hole).  A ``KeyHoleBias`` keeps its two-part form when the
+    kernels can honour it (no gradient needed, or the saved-scores backward applies); otherwise it is densified."""
     q, k, v = _bshd(q, "q"), _bshd(k, "k"), _bshd(v, "v")
     b, sq, h, _ = q.shape
     sk = k.shape[1]
     if k.shape != (b, sk, h, HEAD_DIM) or v.shape != k.shape:
         raise ValueError("q / k / v shape mismatch: {} {} {}".format(tuple(q.shape), tuple(k.shape), tuple(v.shape)))
+    hole = None
+    if isinstance(bias, KeyHoleBias):
+        if need_grad and not scores_fit(b, h, sq, sk):
+            bias = bias.dense()
+        else:
+            bias, hole = bias.slab, bias.hole
     bias, bstr = _bias_view(bias, b, h, sq, sk)
-    return q, k, v, bias, bstr, HEAD_DIM ** -0.5 if scale is None else float(scale)
+    return q, k, v, bias, bstr, HEAD_DIM ** -0.5 if scale is None else float(scale), hole
 
 
 def attention_forward(q, k, v, bias=None, scale=None):
     """Forward only; returns ``(o (B, Sq, H, 64), lse (B, H, Sq))``."""
-    return _forward(*_prepare(q, k, v, bias, scale))[:2]
+    q, k, v, bias, bstr, scale, hole = _prepare(q, k, v, bias, scale)
+    return _forward(q, k, v, bias, bstr, scale, key_hole=hole)[:2]
 
 
 # The backward keeps dS in a transient workspace (5 matrix products) when that workspace is at most this many bytes,
@@ -149,9 +201,10 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, bias, scale):
-        q, k, v, bias_t, bstr, scale = _prepare(q.detach(), k.detach(), v.detach(),
-                                                None if bias is None else bias.detach(), scale)
-        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=any(ctx.needs_input_grad[:3]))
+        need = any(ctx.needs_input_grad[:3])
+        q, k, v, bias_t, bstr, scale, hole = _prepare(q.detach(), k.detach(), v.detach(),
+                                                      None if bias is None else bias.detach(), scale, need_grad=need)
+        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=need, key_hole=hole)
         ctx.save_for_backward(q, k, v, o, lse, bias_t, scores)
         ctx.bstr, ctx.scale = bstr, scale
         return o
@@ -175,9 +228,10 @@ class _PackedSelfAttention(torch.autograd.Function):
         qkv = qkv.detach()
         if not qkv.is_contiguous():
             qkv = qkv.contiguous()
-        q, k, v, bias_t, bstr, scale = _prepare(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2],
-                                                None if bias is None else bias.detach(), scale)
-        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=ctx.needs_input_grad[0])
+        need = ctx.needs_input_grad[0]
+        q, k, v, bias_t, bstr, scale, hole = _prepare(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2],
+                                                      None if bias is None else bias.detach(), scale, need_grad=need)
+        o, lse, scores = _forward(q, k, v, bias_t, bstr, scale, save_scores=need, key_hole=hole)
         ctx.save_for_backward(qkv, o, lse, bias_t, scores)
         ctx.bstr, ctx.scale = bstr, scale
         return o

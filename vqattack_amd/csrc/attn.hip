@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
                                                              const float* __restrict__ v,
                                                              const float* __restrict__ bias, float* __restrict__ o,
                                                              float* __restrict__ lse, float* __restrict__ scores,
-                                                             AttnDims d) {
+                                                             AttnDims d, const int* __restrict__ key_hole) {
   __shared__ float Kbuf[2][kTile * kKs];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -200,6 +200,10 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   f32x16 o0 = {0}, o1 = {0};                               // O^T[dim (+32)][query]
   float m = -INFINITY, mc = 0.0f, l = 0.0f;                // running max, the same times log2 e (0 while -inf), row sum
   const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  // keys [hole_lo, hole_hi) of this batch element are masked (-inf) for every head and query: the padded text tokens of
+  // a question shorter than the batch's text length.  Wave-uniform (SGPRs); with it the additive bias can stay ONE
+  // (1, H, S, S) slab shared by the batch instead of a per-sample (B, H, S, S) copy streamed from HBM by every call.
+  const int hole_lo = key_hole ? key_hole[2 * b] : 0, hole_hi = key_hole ? key_hole[2 * b + 1] : 0;
   f32x16 bcur = {0};
   if (HAS_BIAS && active) bcur = load_bias_tile(bp, 0);
   {
@@ -223,6 +227,13 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
       if (HAS_BIAS && more) bnext = load_bias_tile(bp, k0 + kTile);
       __builtin_amdgcn_sched_barrier(0);         // keep every load ahead of the MFMA chain that hides its latency
       f32x16 st = bcur;                          // S^T = bias + K . (scale Q)^T, key on the accumulator row
+      if (k0 < hole_hi && k0 + kTile > hole_lo) {   // a tile that overlaps the hole (at most two of ~19): -inf goes into
+#pragma unroll                                      // the initial accumulator, so the saved scores carry it too
+        for (int i = 0; i < 16; ++i) {
+          const int key = k0 + acc_row(i, h);
+          st[i] = (key >= hole_lo && key < hole_hi) ? -INFINITY : st[i];
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 32; ++s) st = mfma(Ks[s], qf[s], st);
       if (STORE_S) {                             // the backward's dK / dV kernel starts from these instead of Q . K^T
@@ -718,7 +729,7 @@ long vqa_attn_scores_floats(int B, int H, int Sq, int Sk) {
 
 int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
                  int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
-                 vqa_stream_t stream) {
+                 const int* key_hole, vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !o || !lse || (bias && !bias_strides)) return VQA_ERR_NULL;
   AttnDims d{B, H, Sq, Sk, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], strides[6],
@@ -735,10 +746,10 @@ int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bi
   if (B == 0) return VQA_OK;
   const dim3 grid(static_cast<unsigned>(((Sq + 127) / 128) * H * B));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bias && scores) attn_fwd_kernel<true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
-  else if (bias) attn_fwd_kernel<true, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
-  else if (scores) attn_fwd_kernel<false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
-  else attn_fwd_kernel<false, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d);
+  if (bias && scores) attn_fwd_kernel<true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
+  else if (bias) attn_fwd_kernel<true, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
+  else if (scores) attn_fwd_kernel<false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
+  else attn_fwd_kernel<false, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
   return launch_status();
 }
 

@@ -194,16 +194,56 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(LnBwdArgs A) {
 }
 
 // ---- exact GELU (torch.nn.functional.gelu, approximate='none') and its derivative -------------------------------
+// The two kernels are bound by the vector ALU, not by HBM (113 M elements per image-expert call; the library erff costs
+// ~35 VALU slots per element, the stream itself would take ~60 us): erf is evaluated here branch-free on PAIRS of
+// elements with packed fp32 FMAs (v_pk_fma_f32: two lanes' worth of polynomial per slot).  Coefficients: two minimax
+// polynomials, erf(a) = a + a * P(a^2) below 0.9277 and 1 - exp(Q(|a|)) above, each below 1 ulp of error in fp32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kSqrtHalf = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;      // M_2_SQRTPI * M_SQRT1_2 * 0.5
+constexpr float kLog2e = 1.44269504088896340736f;
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * kSqrtHalf)); }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk(float v) { return f32x2{v, v}; }
 
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * kSqrtHalf));
-  const float pdf = expf(-0.5f * x * x) * kInvSqrt2Pi;
-  return cdf + x * pdf;
+__device__ __forceinline__ f32x2 erf2(f32x2 a) {
+  const f32x2 t = __builtin_elementwise_abs(a);
+  const f32x2 s = a * a;
+  // |a| > 0.9277: erf = 1 - exp(r(t))
+  f32x2 r = pk_fma(pk(-1.72853470e-5f), t, pk(3.83197126e-4f));
+  const f32x2 u = pk_fma(pk(-3.88396438e-3f), t, pk(2.42546219e-2f));
+  r = pk_fma(r, s, u);
+  r = pk_fma(r, t, pk(-1.06777877e-1f));
+  r = pk_fma(r, t, pk(-6.34846687e-1f));
+  r = pk_fma(r, t, pk(-1.28717512e-1f));
+  r = pk_fma(r, t, -t);
+  r = r * pk(kLog2e);
+  f32x2 big = {1.0f - __builtin_amdgcn_exp2f(r[0]), 1.0f - __builtin_amdgcn_exp2f(r[1])};
+  big = f32x2{__builtin_copysignf(big[0], a[0]), __builtin_copysignf(big[1], a[1])};
+  // |a| <= 0.9277: erf = a + a * p(a^2)
+  f32x2 p = pk_fma(pk(-5.96761703e-4f), s, pk(4.99119423e-3f));
+  p = pk_fma(p, s, pk(-2.67681349e-2f));
+  p = pk_fma(p, s, pk(1.12819925e-1f));
+  p = pk_fma(p, s, pk(-3.76125336e-1f));
+  p = pk_fma(p, s, pk(1.28379166e-1f));
+  p = pk_fma(p, a, a);
+  return f32x2{t[0] > 0.927734375f ? big[0] : p[0], t[1] > 0.927734375f ? big[1] : p[1]};
 }
+
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {            // 0.5 x (1 + erf(x / sqrt 2))
+  const f32x2 e = erf2(x * pk(kSqrtHalf));
+  return (pk(0.5f) * x) * (pk(1.0f) + e);
+}
+
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {       // cdf + x pdf
+  const f32x2 cdf = pk(0.5f) * (pk(1.0f) + erf2(x * pk(kSqrtHalf)));
+  const f32x2 q = (x * x) * pk(-0.5f * kLog2e);
+  const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])} * pk(kInvSqrt2Pi);
+  return pk_fma(x, pdf, cdf);
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return gelu2(f32x2{x, x})[0]; }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad2(f32x2{x, x})[0]; }
 
 constexpr int kGeluUnroll = 4;
 
@@ -225,10 +265,16 @@ __global__ __launch_bounds__(kBlock) void gelu_kernel(const f32x4* __restrict__ 
     for (int u = 0; u < kGeluUnroll; ++u) {
       const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
       if (i < n4) {
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = BWD ? vd[u][e] * gelu_grad_f(vh[u][e]) : gelu_f(vh[u][e]);
-        out[i] = r;
+        const f32x2 lo = {vh[u][0], vh[u][1]}, hi = {vh[u][2], vh[u][3]};
+        f32x2 rl, rh;
+        if (BWD) {
+          rl = f32x2{vd[u][0], vd[u][1]} * gelu_grad2(lo);
+          rh = f32x2{vd[u][2], vd[u][3]} * gelu_grad2(hi);
+        } else {
+          rl = gelu2(lo);
+          rh = gelu2(hi);
+        }
+        out[i] = f32x4{rl[0], rl[1], rh[0], rh[1]};
       }
     }
   }

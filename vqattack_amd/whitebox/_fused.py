@@ -86,11 +86,17 @@ class _Call:
         self.spec, self.biases, self.n_text = spec, biases, n_text
 
 
-def _attention_inputs(qkv5, bias):
+def _attention_inputs(qkv5, bias, need_grad):
     q, k, v = qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2]
     b, s, h, _ = q.shape
+    hole = None
+    if isinstance(bias, _attn.KeyHoleBias):
+        if need_grad and not _attn.scores_fit(b, h, s, s):
+            bias = bias.dense()
+        else:
+            bias, hole = bias.slab, bias.hole
     bias_t, bstr = _attn._bias_view(None if bias is None else bias.detach(), b, h, s, s)
-    return q, k, v, bias_t, bstr
+    return q, k, v, bias_t, bstr, hole
 
 
 def _forward(x0, call, save):
@@ -116,8 +122,8 @@ def _forward(x0, call, save):
         qkv = torch.addmm(lay.bqkv, y, lay.wqkv.t())
         del y
         qkv5 = qkv.view(b, s, 3, spec.heads, _attn.HEAD_DIM)
-        q, k, v, bias_t, bstr = _attention_inputs(qkv5, None if call.biases is None else call.biases[li])
-        o, lse, scores = _attn._forward(q, k, v, bias_t, bstr, scale, save_scores=save)
+        q, k, v, bias_t, bstr, hole = _attention_inputs(qkv5, None if call.biases is None else call.biases[li], save)
+        o, lse, scores = _attn._forward(q, k, v, bias_t, bstr, scale, save_scores=save, key_hole=hole)
         p = torch.addmm(lay.bproj, o.view(rows, d), lay.wproj.t())
         x1 = torch.empty(b, s, d, dtype=f32, device=dev)
         mean2, rstd2 = torch.empty(rows, dtype=f32, device=dev), torch.empty(rows, dtype=f32, device=dev)

@@ -40,6 +40,8 @@ def mha(q, k, v, bias=None):
         if d == _attn.HEAD_DIM:
             return _attn.attention(q, k, v, bias)
         return _attn.attention(_pad(q), _pad(k), _pad(v), bias, scale=d ** -0.5)[..., :d]
+    if isinstance(bias, _attn.KeyHoleBias):
+        bias = bias.dense()
     o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias)
     return o.transpose(1, 2)
 

@@ -267,14 +267,28 @@ class FrozenVlmo(nn.Module):
           * when every question of the batch has the same padding pattern (batches are bucketed by schedule and
             length) the mask is ONE (1, heads, S, S) slab expanded over the batch with stride 0: 18 MB per layer that
             stays cache-resident instead of a (B, heads, S, S) tensor (1.17 GB at batch 64) streamed by every
-            forward and backward attention kernel.  Otherwise it is materialised per sample (HBM is 288 GB).
+            forward attention kernel;
+          * a RAGGED batch on the GPU (questions of different lengths, padded at the end -- what a tokenizer produces)
+            keeps that one slab too: the padded text keys of sample b are the range [length_b, n_text), handed to the
+            attention kernel as a per-sample "key hole" (``attention.KeyHoleBias``) instead of being written into a
+            per-sample copy of the slab.  Only masks that are not of that form (or host tensors: the CPU oracle's
+            model) are materialised per sample.
         """
+        from ..attention import KeyHoleBias
         b, n_text = text_masks.shape
         dev = text_masks.device
         s = n_text + self.cfg.n_image_tokens
         s_pad = (s + 31) // 32 * 32
         keep = torch.cat([text_masks.bool(), torch.ones(b, self.cfg.n_image_tokens, dtype=torch.bool, device=dev)], dim=1)
         shared = bool((keep == keep[:1]).all())          # one host sync per text batch
+        hole = None
+        if not shared and dev.type == "cuda":
+            lengths = text_masks.bool().sum(dim=1)
+            prefix = text_masks.bool() == (torch.arange(n_text, device=dev)[None, :] < lengths[:, None])
+            if bool(prefix.all()):
+                hole = torch.stack([lengths, torch.full_like(lengths, n_text)], dim=1).to(torch.int32).contiguous()
+                shared = True                            # the slab carries the relative-position bias only
+                keep = torch.ones_like(keep)
         rows = keep[:1] if shared else keep
         pad = torch.zeros(rows.shape[0], 1, 1, s, device=dev).masked_fill(~rows[:, None, None, :], float("-inf"))
         if n_text == self.cfg.max_text_len:
@@ -289,7 +303,8 @@ class FrozenVlmo(nn.Module):
             store = torch.zeros(rows.shape[0], self.cfg.heads, s, s_pad, device=dev)
             store[..., :s] = pad + rel[li].unsqueeze(0)
             view = store[..., :s]
-            out.append(view.expand(b, -1, -1, -1) if shared else view)
+            view = view.expand(b, -1, -1, -1) if shared else view
+            out.append(view if hole is None else KeyHoleBias(view, hole))
         return out
 
     def encode(self, image, text_embeds, text_masks, bias=None):
