@@ -58,7 +58,9 @@ const char* vqa_error_string(int code);
  *             n = 1..8 workgroups per CU
  *   option 7: rows in flight per wavefront in the cosine-loss kernel (1 or 2; default 2)
  *   option 8: non-temporal hints of the cosine-loss kernel, bit0 = loads of `a`, bit1 = gradient stores, bit2 = loads
- *             of the targets `b` (default 4) */
+ *             of the targets `b` (default 4)
+ *   option 9: dQ-from-dS^T attention kernel, 1 = dS^T tile staged through LDS with 16-byte loads (default), 0 = direct
+ *             dword loads into the MFMA operand (round 3's form) */
 int vqa_set_option(int option, int value);
 #endif
 

@@ -261,3 +261,23 @@ def test_mixed_update_runs_and_paraphrase_following(monkeypatch):
     assert changed and ids[1].tolist()[:6] == [101, 9999, 3609, 103, 9999, 102]
     assert not attack._follow_substitutions(tasks, [1], ids, msk, [[], []])
     assert task.words_mlm[0] == (2054,)                                       # the caller's task is untouched
+
+
+def test_key_hole_bias_densifies_to_the_per_sample_padding_mask():
+    """``attention.KeyHoleBias`` (one relative-position slab + per-sample masked key range, what a ragged batch hands to
+    the GPU attention kernel) must describe exactly the per-sample additive mask the host path builds
+    (``FrozenVlmo.attention_bias`` on CPU tensors: relative-position bias + -inf on padded text keys,
+    multiway_transformer.py:88-118 / vlmo_module.py:807-814)."""
+    import torch
+    from vqattack_amd.attention import KeyHoleBias
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, vlmo_tiny
+    model = FrozenVlmo(vlmo_tiny(), seed=0)
+    masks = torch.tensor([[1, 1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1, 1]])
+    dense = model.attention_bias(masks)                     # host tensors: materialised per sample
+    full = model.attention_bias(torch.ones_like(masks))     # no padding: the shared slab
+    lengths = masks.sum(dim=1)
+    hole = torch.stack([lengths, torch.full_like(lengths, masks.shape[1])], dim=1).to(torch.int32)
+    for li in range(model.cfg.depth):
+        assert not isinstance(dense[li], KeyHoleBias)
+        got = KeyHoleBias(full[li], hole).dense()
+        assert got.shape == dense[li].shape and torch.equal(got, dense[li])

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vqattack_amd import attention  # noqa: E402
+from vqattack_amd import _hip, attention  # noqa: E402
 
 B, H, S, D = 64, 12, int(os.environ.get("S", "587")), 64
 
@@ -65,9 +65,15 @@ def main():
                               TFLOPs=round(flops_fwd / ms / 1e9, 1))), flush=True)
         o, lse, scores = attention._forward(q, k, v, bias, bstr, D ** -0.5, save_scores=True)
         dqkv = torch.empty_like(qkv)
-        for what, kw in (("hip bwd kernels, from saved scores", dict(scores=scores)),
-                         ("hip bwd kernels, dS workspace only", dict()),
-                         ("hip bwd kernels, recompute form", dict(workspace=False))):
+        forms = [("hip bwd kernels, from saved scores", dict(scores=scores), None),
+                 ("hip bwd kernels, dS workspace only", dict(), None),
+                 ("hip bwd kernels, recompute form", dict(workspace=False), None)]
+        if _hip.set_option(9, 1):        # tuning build (VQA_TUNING_LIB=1): A/B of the dQ-from-dS^T kernel, alternating
+            forms = [("hip bwd kernels, from saved scores, dQ kernel with direct dword loads (round 3)", dict(scores=scores), 0),
+                     ("hip bwd kernels, from saved scores, dQ kernel staged through LDS", dict(scores=scores), 1)] * 3 + forms[1:]
+        for what, kw, knob in forms:
+            if knob is not None:
+                _hip.set_option(9, knob)
             ms = timeit(lambda: attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
                                                     dqkv[:, :, 2], D ** -0.5, **kw))
             print(json.dumps(dict(what=what, ms=round(ms, 3), TFLOPs=round(2.5 * flops_fwd / ms / 1e9, 1))),

@@ -39,8 +39,8 @@ def report(name, nbytes, ms, note=""):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--sections", default="linf,copy,norm,cos,ce,text",
-                    help="comma list of: linf, copy, norm, cos, ce, text")
+    ap.add_argument("--sections", default="linf,copy,norm,cos,ce,text,block",
+                    help="comma list of: linf, copy, norm, cos, ce, text, block")
     args = ap.parse_args()
     sections = set(args.sections.split(","))
     b = args.batch
@@ -65,6 +65,8 @@ def main():
         ce_section(b)
     if "text" in sections:
         text_section(b)
+    if "block" in sections:
+        block_section(b)
 
 
 def copy_probes(x, x0, g, out, n):
@@ -234,6 +236,50 @@ def ce_section(b):
         F.cross_entropy(lg, labels[0]).backward()
     report("torch F.cross_entropy fwd+bwd (K=1), same bytes basis", 8 * rows * 30522, timeit(torch_ce),
            "PyTorch-ROCm eager reference for the op the kernel replaces")
+
+
+def block_section(b):
+    """The white box's block glue (csrc/block.hip) at the VLMO-base bench layout: S = 14 text + 577 image tokens, D = 768,
+    hidden 3072.  Algorithmic bytes = every operand once."""
+    s, t, d = 591, 14, 768
+    rows = b * s
+    dev = "cuda"
+    x, r = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
+    gam, bet, sc = torch.ones(d, device=dev), torch.zeros(d, device=dev), torch.ones(d, device=dev)
+    y, x_out = torch.empty(rows, d, device=dev), torch.empty(rows, d, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    e = 4 * rows * d
+    report("vqa_ln_fwd (LayerNorm only)", 2 * e, timeit(lambda: ops.ln_fwd(x, gam, bet, y, mean, rstd, 1e-6)))
+    report("vqa_ln_fwd (residual add of the previous branch + LayerNorm)", 4 * e,
+           timeit(lambda: ops.ln_fwd(x, gam, bet, y, mean, rstd, 1e-6, r0=r, rscale=sc, x_out=x_out)))
+    y0, y1 = torch.empty(b * t, d, device=dev), torch.empty(b * (s - t), d, device=dev)
+    report("vqa_ln_fwd (residual add + text / image LayerNorm, split output)", 4 * e,
+           timeit(lambda: ops.ln_fwd(x, gam, bet, y0, mean, rstd, 1e-6, r0=r, rscale=sc, x_out=x_out, gamma1=gam,
+                                     beta1=bet, y1=y1, period=s, split=t)))
+    ops.ln_fwd(x, gam, bet, y, mean, rstd, 1e-6)
+    dy, g_a, g_inj = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
+    dx, dr = torch.empty(rows, d, device=dev), torch.empty(rows, d, device=dev)
+    report("vqa_ln_bwd (LN backward + residual gradient + layer-scaled branch gradient)", 5 * e,
+           timeit(lambda: ops.ln_bwd(dy, x, mean, rstd, gam, dx, g_a=g_a, rscale=sc, dr0=dr)))
+    dr0, dr1 = torch.empty(b * t, d, device=dev), torch.empty(b * (s - t), d, device=dev)
+    report("vqa_ln_bwd (+ the loss gradient of the feature map, split branch gradient)", 6 * e,
+           timeit(lambda: ops.ln_bwd(dy, x, mean, rstd, gam, dx, g_a=g_a, g_inj=g_inj, rscale=sc, dr0=dr0, dr1=dr1,
+                                     period=s, split=t)))
+
+    def eager_stage():
+        # what autograd's eager ops run for the same stage: addcmul, layer_norm, two slice copies
+        x1 = torch.addcmul(x.view(b, s, d), sc, r.view(b, s, d))
+        return torch.nn.functional.layer_norm(x1[:, :t].contiguous(), (d,), gam, bet, 1e-6), \
+            torch.nn.functional.layer_norm(x1[:, t:].contiguous(), (d,), gam, bet, 1e-6)
+    report("eager ATen chain for the split forward stage (addcmul + slice copies + layer_norm), same 16 B/el basis",
+           4 * e, timeit(eager_stage), "what vqa_ln_fwd replaces")
+    del x, r, y, x_out, dy, g_a, g_inj, dx, dr, y0, y1, dr0, dr1
+    n = b * 577 * 3072                       # the image expert's hidden activations
+    h, da = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    a = torch.empty_like(h)
+    report("vqa_gelu_fwd (image expert hidden, {} x 3072)".format(b * 577), 8 * n, timeit(lambda: ops.gelu_fwd(h, out=a)))
+    report("vqa_gelu_bwd (in place on da)", 12 * n, timeit(lambda: ops.gelu_bwd(h, da)))
+    report("torch F.gelu, same bytes", 8 * n, timeit(lambda: torch.nn.functional.gelu(h)), "allocates its output")
 
 
 def text_section(b):

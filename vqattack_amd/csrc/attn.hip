@@ -439,6 +439,102 @@ __global__ __launch_bounds__(kBlock) void attn_delta_kernel(const float* __restr
   if (ok && (threadIdx.x & 15) == 0) delta[row] = t;
 }
 
+// dQ^T += K^T . dS^T with the dS^T tile STAGED THROUGH LDS (round 4).  The direct form below feeds the MFMA's B operand
+// with 16 dword loads per lane and tile (lane = query): 4-byte accesses reach roughly half the rate of 16-byte ones on
+// this chip (MI355X_MICROARCH.md), and the kernel -- 1.3 GB of dS^T for 34 GFLOP -- sat at 3.1 TB/s, neither on the HBM
+// nor on the matrix roof.  Here the workgroup fetches a tile's 32 key rows x 128 queries (16 KB, rows of 512 contiguous
+// bytes) with four 16-byte loads per thread, prefetched a tile ahead into registers like the K tile, publishes it in LDS
+// (row stride 136 floats: the two lane halves read rows 4 apart, 4 * 136 = 32 mod 64 banks -> conflict-free), and every
+// lane reads its 16 B-operand values back with ds_read_b32.  Same products in the same order: results are bitwise those
+// of the direct form.
+constexpr int kDsStride = 136;
+
+struct DsRegs {
+  f32x4 v[4];
+};
+
+__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const float* __restrict__ k,
+                                                                       const float* __restrict__ ds,
+                                                                       float* __restrict__ dq, AttnDims d, long dq_sb,
+                                                                       long dq_ss, long dq_sh) {
+  __shared__ __attribute__((aligned(16))) float Kbuf[2][kTile * kVi];
+  __shared__ __attribute__((aligned(16))) float Dbuf[2][kTile * kDsStride];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int r = lane & 31, h = lane >> 5;
+  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int b = bc.b, head = bc.head;
+  const int Q0 = bc.blk * 128;
+  const int q0 = Q0 + wave * kTile;
+  const int qi = q0 + r;
+  const bool active = q0 < d.Sq;
+  const float* kb = k + b * d.k_sb + head * d.k_sh;
+  const long pitch = ds_pitch(d.Sq);
+  const float* slab = ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * pitch;     // uniform
+  // staging role of this thread: key row (t / 32) + 8 j of the tile, queries Q0 + 4 (t % 32) .. + 3
+  const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
+  const bool col_ok = Q0 + scol < pitch;                     // the last query block may reach beyond the row pitch
+  const float* sp = slab + static_cast<long>(srow) * pitch + (col_ok ? Q0 + scol : 0);
+  auto load_ds = [&](int k0) {
+    DsRegs t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                  // read exactly once
+      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + static_cast<long>(k0 + 8 * j) * pitch));
+    return t;
+  };
+  auto store_ds = [&](float* buf, const DsRegs& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
+  };
+  f32x16 dq0 = {0}, dq1 = {0};
+  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  {
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk);
+    const DsRegs td = load_ds(0);
+    store_tile_interleaved(Kbuf[0], tk, 1.0f);
+    store_ds(Dbuf[0], td);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const bool more = kt + 1 < n_tiles;
+    const float* Kc = Kbuf[kt & 1] + 4 * h * kVi + 2 * r;
+    const float* Dc = Dbuf[kt & 1] + 4 * h * kDsStride + wave * kTile + r;
+    TileRegs tk;
+    DsRegs td;
+    if (more) {                                  // in flight while this tile's 32 MFMAs run
+      tk = load_tile_clamped(kb, d.k_ss, (kt + 1) * kTile, d.Sk);
+      td = load_ds((kt + 1) * kTile);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2);
+        const f32x2 kk = *reinterpret_cast<const f32x2*>(Kc + row * kVi);
+        const float dsv = Dc[row * kDsStride];
+        dq0 = mfma(kk[0], dsv, dq0);
+        dq1 = mfma(kk[1], dsv, dq1);
+      }
+    }
+    if (more) {                                  // the other buffers were last read one tile ago, a barrier in between
+      store_tile_interleaved(Kbuf[(kt + 1) & 1], tk, 1.0f);
+      store_ds(Dbuf[(kt + 1) & 1], td);
+    }
+    __syncthreads();
+  }
+  if (qi < d.Sq) {
+    float* dp_ = dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dim = 8 * g + 4 * h;
+      f32x4 a = {dq0[4 * g] * d.scale, dq0[4 * g + 1] * d.scale, dq0[4 * g + 2] * d.scale, dq0[4 * g + 3] * d.scale};
+      f32x4 c = {dq1[4 * g] * d.scale, dq1[4 * g + 1] * d.scale, dq1[4 * g + 2] * d.scale, dq1[4 * g + 3] * d.scale};
+      *reinterpret_cast<f32x4*>(dp_ + dim) = a;
+      *reinterpret_cast<f32x4*>(dp_ + 32 + dim) = c;
+    }
+  }
+}
+
+#ifdef VQA_TUNING   // round 3's direct form, kept for the A/B of tools/attn_bench.py (option 9); not in the shipped library
 // dQ^T += K^T . dS^T over the key tiles; one workgroup = 4 waves = 128 queries of one (batch, head).  No scores, no
 // exponentials: per tile 16 coalesced dword loads of dS^T (prefetched a tile ahead), 16 LDS reads, 32 MFMAs.
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const float* __restrict__ k,
@@ -513,6 +609,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const fl
     }
   }
 }
+#endif  // VQA_TUNING
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // One workgroup = 4 waves = 128 keys of one (batch, head); loop over query tiles of 32.  Key on the lane:
@@ -708,7 +805,16 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
 
 using namespace vqa;
 
+VQA_KNOB g_attn_dq_staged = 1;      // option 9 (tuning build): 1 = dS^T tile staged through LDS, 0 = direct dword loads
+
 extern "C" {
+
+#ifdef VQA_TUNING
+int vqa_attn_set_option(int value) {     // reached through vqa_set_option(9, value)
+  g_attn_dq_staged = value ? 1 : 0;
+  return VQA_OK;
+}
+#endif
 
 static int check_attn(const float* q, const float* k, const float* v, const AttnDims& d) {
   if (!q || !k || !v) return VQA_ERR_NULL;
@@ -812,7 +918,11 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
       attn_bwd_dkv_kernel<false, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
                                                                      g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
                                                                      ds_ws, nullptr);
-    attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
+#ifdef VQA_TUNING
+    if (!g_attn_dq_staged) attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
+    else
+#endif
+    attn_bwd_dq_staged_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
   } else if (bias) {                             // no workspace: 7 products, both kernels recompute the scores
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
                                                      g[2]);

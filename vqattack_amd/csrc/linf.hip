@@ -226,6 +226,7 @@ extern "C" {
 int vqa_ce_set_threads(int threads);   // ce.hip
 int vqa_ce_set_variant(int variant);   // ce.hip
 int vqa_loss_set_option(int which, int value);   // loss.hip
+int vqa_attn_set_option(int value);              // attn.hip
 
 int vqa_set_option(int option, int value) {
   switch (option) {
@@ -251,6 +252,8 @@ int vqa_set_option(int option, int value) {
     case 7:
     case 8:
       return vqa_loss_set_option(option, value);
+    case 9:
+      return vqa_attn_set_option(value);
     default:
       return VQA_ERR_SHAPE;
   }
