@@ -60,7 +60,9 @@ const char* vqa_error_string(int code);
  *   option 8: non-temporal hints of the cosine-loss kernel, bit0 = loads of `a`, bit1 = gradient stores, bit2 = loads
  *             of the targets `b` (default 4)
  *   option 9: dQ-from-dS^T attention kernel, 1 = dS^T tile staged through LDS with 16-byte loads (default), 0 = direct
- *             dword loads into the MFMA operand (round 3's form) */
+ *             dword loads into the MFMA operand (round 3's form)
+ *   option 10: block-glue kernels, bit0 = non-temporal loads of the activation streams, bit1 = non-temporal stores of GELU
+ *             results larger than the Infinity Cache (default 3) */
 int vqa_set_option(int option, int value);
 #endif
 

@@ -69,3 +69,42 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert asr is not None and 0.0 <= asr <= 1.0
     assert abs(asr * world * batch * steps - round(asr * world * batch * steps)) < 1e-4, "ASR is over 2 x batch x steps bits"
     assert rec["roofline"] is not None and rec["roofline"]["launches"] == 6 * steps and rec["vs_baseline"] is None
+
+
+def _plain_invocation(out_path, argv):
+    """``python bench.py --gpus 2 ...`` WITHOUT a launcher environment, from a process that has not touched the GPU (the
+    fork server's child): bench.py must start the two ranks itself (torch.distributed.run as a child process)."""
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        os.environ.pop(k, None)
+    os.environ.update(VQA_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")      # two ranks share the one GPU of the test box
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py"] + list(argv)
+    out = open(out_path, "w")
+    os.dup2(out.fileno(), 1)
+    os.dup2(out.fileno(), 2)
+    import bench
+    bench.main()                                  # sys.exit(launcher's code)
+
+
+def test_plain_gpus_2_invocation_starts_two_ranks(tmp_path):
+    """The driver may run the scaling bench as a plain ``python bench.py --gpus N``: that must be an N-rank run (here
+    N = 2 on one GPU, gloo for the collectives), never a silent 1-GPU run under an N-GPU label."""
+    ctx = multiprocessing.get_context("forkserver")
+    out = str(tmp_path / "plain.out")
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--model", "vlmo_tiny", "--batch", "4", "--pgd-steps", "6",
+            "--no-cpu-baseline", "--no-b256"]
+    p = ctx.Process(target=_plain_invocation, args=(out, argv))
+    p.start()
+    p.join(timeout=420)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("the launcher did not finish within 420 s")
+    text = open(out).read()
+    assert p.exitcode == 0, text[-3000:]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collective"]["world"] == 2 and rec["collective"]["backend"] == "gloo"
+    assert rec["value"] > 0 and rec["config"]["batch_per_gpu"] == 4

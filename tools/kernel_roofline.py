@@ -241,6 +241,17 @@ def ce_section(b):
 def block_section(b):
     """The white box's block glue (csrc/block.hip) at the VLMO-base bench layout: S = 14 text + 577 image tokens, D = 768,
     hidden 3072.  Algorithmic bytes = every operand once."""
+    for nt in (0, 1, 3):                      # tuning build: A/B of the non-temporal hints; shipped build: one pass
+        tuned = _hip.set_option(10, nt)
+        if tuned or nt == 3:
+            _block_pass(b, " [nt mask {}]".format(nt) if tuned else "")
+
+
+def _block_pass(b, tag):
+    _report = globals()["report"]
+
+    def report(name, *a, **kw):
+        _report(name + tag, *a, **kw)
     s, t, d = 591, 14, 768
     rows = b * s
     dev = "cuda"

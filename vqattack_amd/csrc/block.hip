@@ -43,12 +43,17 @@ __device__ __forceinline__ SegRow seg_row(const SplitMap& m, int row) {
   return SegRow{1, static_cast<long>(b) * (m.period - m.split) + (s - m.split)};
 }
 
-template <int NCH>
+// NT: non-temporal load -- for the activation streams, which a launch reads exactly once (parameter vectors stay plain:
+// every row re-reads them from the cache)
+template <int NCH, bool NT = false>
 __device__ __forceinline__ void load_vec(f32x4 (&v)[NCH], const float* __restrict__ p, int lane, int D) {
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int d = (k * kWave + lane) * 4;
-    v[k] = d < D ? *reinterpret_cast<const f32x4*>(p + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (d < D)
+      v[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + d)) : *reinterpret_cast<const f32x4*>(p + d);
+    else
+      v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 }
 
@@ -71,20 +76,20 @@ struct LnFwdArgs {
   float eps;
 };
 
-template <int NCH>
+template <int NCH, bool NT>
 __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(LnFwdArgs A) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const float inv_d = 1.0f / static_cast<float>(A.D);
   for (int row = blockIdx.x * kRowsPerBlock + wave; row < A.rows; row += gridDim.x * kRowsPerBlock) {
     f32x4 x[NCH];
-    load_vec<NCH>(x, A.x + static_cast<long>(row) * A.D, lane, A.D);
+    load_vec<NCH, NT>(x, A.x + static_cast<long>(row) * A.D, lane, A.D);
     SegRow sr{0, row};
     if (A.map.period > 0) sr = seg_row(A.map, row);
     if (A.r0) {                                             // prologue: the residual add of the previous branch
       const float* rp = A.r1 ? (sr.seg ? A.r1 : A.r0) + sr.row * A.D : A.r0 + static_cast<long>(row) * A.D;
       f32x4 r[NCH];
-      load_vec<NCH>(r, rp, lane, A.D);
+      load_vec<NCH, NT>(r, rp, lane, A.D);
       if (A.rscale) {
         f32x4 s[NCH];
         load_vec<NCH>(s, A.rscale, lane, A.D);
@@ -134,7 +139,7 @@ struct LnBwdArgs {
   SplitMap map;
 };
 
-template <int NCH>
+template <int NCH, bool NT>
 __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(LnBwdArgs A) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(LnBwdArgs A) {
     if (A.map.period > 0) sr = seg_row(A.map, row);
     const long off = static_cast<long>(row) * A.D;
     f32x4 xh[NCH], g[NCH];
-    load_vec<NCH>(xh, A.x + off, lane, A.D);
-    load_vec<NCH>(g, A.dy1 ? (sr.seg ? A.dy1 : A.dy0) + sr.row * A.D : A.dy0 + off, lane, A.D);
+    load_vec<NCH, NT>(xh, A.x + off, lane, A.D);
+    load_vec<NCH, NT>(g, A.dy1 ? (sr.seg ? A.dy1 : A.dy0) + sr.row * A.D : A.dy0 + off, lane, A.D);
     {
       f32x4 w[NCH];
       load_vec<NCH>(w, (A.gamma1 && sr.seg) ? A.gamma1 : A.gamma0, lane, A.D);
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(LnBwdArgs A) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[k][e] = rstd * ((g[k][e] - c1) - xh[k][e] * c2);
     if (A.g_a) {                                            // gradient arriving over the residual path
-      load_vec<NCH>(xh, A.g_a + off, lane, A.D);
+      load_vec<NCH, NT>(xh, A.g_a + off, lane, A.D);
 #pragma unroll
       for (int k = 0; k < NCH; ++k) g[k] = g[k] + xh[k];
     }
     if (A.g_inj) {                                          // the loss kernel's gradient of this feature map
-      load_vec<NCH>(xh, A.g_inj + off, lane, A.D);
+      load_vec<NCH, NT>(xh, A.g_inj + off, lane, A.D);
 #pragma unroll
       for (int k = 0; k < NCH; ++k) g[k] = g[k] + xh[k];
     }
@@ -247,9 +252,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad2(f32x2{
 
 constexpr int kGeluUnroll = 4;
 
-template <bool BWD>
+// NT bit0: non-temporal loads of h (and of da unless the update is in place), bit1: non-temporal stores (results larger
+// than the 256 MB Infinity Cache cannot stay resident for the consuming GEMM anyway: the step kernel's rule, section 4)
+template <bool BWD, int NT>
 __global__ __launch_bounds__(kBlock) void gelu_kernel(const f32x4* __restrict__ h, const f32x4* da, f32x4* out,
-                                                      size_t n4) {
+                                                      size_t n4, bool in_place) {
   const size_t tile = static_cast<size_t>(kBlock) * kGeluUnroll;
   for (size_t base = static_cast<size_t>(blockIdx.x) * tile; base < n4; base += static_cast<size_t>(gridDim.x) * tile) {
     f32x4 vh[kGeluUnroll], vd[kGeluUnroll];
@@ -257,8 +264,8 @@ __global__ __launch_bounds__(kBlock) void gelu_kernel(const f32x4* __restrict__ 
     for (int u = 0; u < kGeluUnroll; ++u) {
       const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
       if (i < n4) {
-        vh[u] = h[i];
-        if (BWD) vd[u] = da[i];
+        vh[u] = (NT & 1) ? __builtin_nontemporal_load(&h[i]) : h[i];
+        if (BWD) vd[u] = ((NT & 1) && !in_place) ? __builtin_nontemporal_load(&da[i]) : da[i];
       }
     }
 #pragma unroll
@@ -274,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void gelu_kernel(const f32x4* __restrict__ 
           rl = gelu2(lo);
           rh = gelu2(hi);
         }
-        out[i] = f32x4{rl[0], rl[1], rh[0], rh[1]};
+        const f32x4 res = {rl[0], rl[1], rh[0], rh[1]};
+        if (NT & 2) __builtin_nontemporal_store(res, &out[i]);
+        else out[i] = res;
       }
     }
   }
@@ -287,6 +296,8 @@ __global__ __launch_bounds__(kBlock) void gelu_tail_kernel(const float* __restri
   if (i < n) out[i] = BWD ? da[i] * gelu_grad_f(h[i]) : gelu_f(h[i]);
 }
 
+VQA_KNOB g_block_nt = 3;    // option 10 (tuning build): bit0 nt loads of the activation streams, bit1 nt stores of large GELU results
+
 template <bool BWD>
 static int launch_gelu(const float* h, const float* da, float* out, size_t n, vqa_stream_t stream) {
   if (!h || !out || (BWD && !da)) return VQA_ERR_NULL;
@@ -296,8 +307,21 @@ static int launch_gelu(const float* h, const float* da, float* out, size_t n, vq
   size_t done = 0;
   if (aligned16(h) && aligned16(out) && (!BWD || aligned16(da)) && n >= 4) {
     const size_t n4 = n / 4;
-    gelu_kernel<BWD><<<blocks_for(n4, kBlock * kGeluUnroll), kBlock, 0, st>>>(
-        reinterpret_cast<const f32x4*>(h), reinterpret_cast<const f32x4*>(da), reinterpret_cast<f32x4*>(out), n4);
+    const int grid = blocks_for(n4, kBlock * kGeluUnroll);
+    auto h4 = reinterpret_cast<const f32x4*>(h);
+    auto d4 = reinterpret_cast<const f32x4*>(da);
+    auto o4 = reinterpret_cast<f32x4*>(out);
+    const bool in_place = static_cast<const void*>(da) == static_cast<const void*>(out);
+    int nt = g_block_nt & 1;
+    if ((g_block_nt & 2) && n * sizeof(float) > (256ull << 20)) nt |= 2;
+    switch (nt) {
+#ifdef VQA_TUNING
+      case 0: gelu_kernel<BWD, 0><<<grid, kBlock, 0, st>>>(h4, d4, o4, n4, in_place); break;
+      case 2: gelu_kernel<BWD, 2><<<grid, kBlock, 0, st>>>(h4, d4, o4, n4, in_place); break;
+#endif
+      case 1: gelu_kernel<BWD, 1><<<grid, kBlock, 0, st>>>(h4, d4, o4, n4, in_place); break;
+      default: gelu_kernel<BWD, 3><<<grid, kBlock, 0, st>>>(h4, d4, o4, n4, in_place); break;
+    }
     done = n4 * 4;
   }
   if (done < n)
@@ -337,11 +361,22 @@ int vqa_ln_fwd(const float* x, const float* r0, const float* r1, const float* rs
               SplitMap{static_cast<int>(period), static_cast<int>(split)}, eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = row_grid(rows);
+#ifdef VQA_TUNING
+  if (!(g_block_nt & 1)) {
+    switch ((D + 255) / 256) {
+      case 1: ln_fwd_kernel<1, false><<<grid, kBlock, 0, st>>>(A); break;
+      case 2: ln_fwd_kernel<2, false><<<grid, kBlock, 0, st>>>(A); break;
+      case 3: ln_fwd_kernel<3, false><<<grid, kBlock, 0, st>>>(A); break;
+      default: ln_fwd_kernel<4, false><<<grid, kBlock, 0, st>>>(A); break;
+    }
+    return launch_status();
+  }
+#endif
   switch ((D + 255) / 256) {
-    case 1: ln_fwd_kernel<1><<<grid, kBlock, 0, st>>>(A); break;
-    case 2: ln_fwd_kernel<2><<<grid, kBlock, 0, st>>>(A); break;
-    case 3: ln_fwd_kernel<3><<<grid, kBlock, 0, st>>>(A); break;
-    default: ln_fwd_kernel<4><<<grid, kBlock, 0, st>>>(A); break;
+    case 1: ln_fwd_kernel<1, true><<<grid, kBlock, 0, st>>>(A); break;
+    case 2: ln_fwd_kernel<2, true><<<grid, kBlock, 0, st>>>(A); break;
+    case 3: ln_fwd_kernel<3, true><<<grid, kBlock, 0, st>>>(A); break;
+    default: ln_fwd_kernel<4, true><<<grid, kBlock, 0, st>>>(A); break;
   }
   return launch_status();
 }
@@ -363,14 +398,33 @@ int vqa_ln_bwd(const float* dy0, const float* dy1, const float* x, const float* 
               SplitMap{static_cast<int>(period), static_cast<int>(split)}};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = row_grid(rows);
+#ifdef VQA_TUNING
+  if (!(g_block_nt & 1)) {
+    switch ((D + 255) / 256) {
+      case 1: ln_bwd_kernel<1, false><<<grid, kBlock, 0, st>>>(A); break;
+      case 2: ln_bwd_kernel<2, false><<<grid, kBlock, 0, st>>>(A); break;
+      case 3: ln_bwd_kernel<3, false><<<grid, kBlock, 0, st>>>(A); break;
+      default: ln_bwd_kernel<4, false><<<grid, kBlock, 0, st>>>(A); break;
+    }
+    return launch_status();
+  }
+#endif
   switch ((D + 255) / 256) {
-    case 1: ln_bwd_kernel<1><<<grid, kBlock, 0, st>>>(A); break;
-    case 2: ln_bwd_kernel<2><<<grid, kBlock, 0, st>>>(A); break;
-    case 3: ln_bwd_kernel<3><<<grid, kBlock, 0, st>>>(A); break;
-    default: ln_bwd_kernel<4><<<grid, kBlock, 0, st>>>(A); break;
+    case 1: ln_bwd_kernel<1, true><<<grid, kBlock, 0, st>>>(A); break;
+    case 2: ln_bwd_kernel<2, true><<<grid, kBlock, 0, st>>>(A); break;
+    case 3: ln_bwd_kernel<3, true><<<grid, kBlock, 0, st>>>(A); break;
+    default: ln_bwd_kernel<4, true><<<grid, kBlock, 0, st>>>(A); break;
   }
   return launch_status();
 }
+
+#ifdef VQA_TUNING
+int vqa_block_set_option(int value) {    // reached through vqa_set_option(10, value)
+  if (value < 0 || value > 3) return VQA_ERR_SHAPE;
+  g_block_nt = value;
+  return VQA_OK;
+}
+#endif
 
 int vqa_gelu_fwd(const float* h, float* a, size_t n, vqa_stream_t stream) {
   clear_stale_error();

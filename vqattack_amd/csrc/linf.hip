@@ -227,6 +227,7 @@ int vqa_ce_set_threads(int threads);   // ce.hip
 int vqa_ce_set_variant(int variant);   // ce.hip
 int vqa_loss_set_option(int which, int value);   // loss.hip
 int vqa_attn_set_option(int value);              // attn.hip
+int vqa_block_set_option(int value);             // block.hip
 
 int vqa_set_option(int option, int value) {
   switch (option) {
@@ -254,6 +255,8 @@ int vqa_set_option(int option, int value) {
       return vqa_loss_set_option(option, value);
     case 9:
       return vqa_attn_set_option(value);
+    case 10:
+      return vqa_block_set_option(value);
     default:
       return VQA_ERR_SHAPE;
   }
