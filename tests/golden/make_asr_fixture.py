@@ -59,9 +59,13 @@ def main():
     ap.add_argument("--seed", type=int, default=23)
     ap.add_argument("--budget", type=int, default=40)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--cache", default=os.path.join(ROOT, ".asr_cache"))
+    ap.add_argument("--cache", default=os.path.join(ROOT, "gpurun_out", "asr_cache"))   # gpurun_out/ never travels to the GPU box
     ap.add_argument("--out", default=None)
+    ap.add_argument("--sizes", default=None,
+                    help="comma list of closed-answer-set sizes to score (default: CANDIDATE_SIZES); the attack results are "
+                         "cached, so re-scoring with other sizes costs minutes")
     args = ap.parse_args()
+    sizes = [int(v) for v in args.sizes.split(",")] if args.sizes else CANDIDATE_SIZES
     torch.set_num_threads(args.threads)
     from oracle import attack_loop
     from vqattack_amd.attack import text_update
@@ -123,12 +127,12 @@ def main():
                     _, states = black.encode(img, black.text_embeddings(tid), masks[s:s + 1])
                     store.append(black.vqa_classifier(black.pooled(states))[0])
         lc, la = torch.stack(logits_clean), torch.stack(logits_adv)
-        for k in CANDIDATE_SIZES:
+        for k in sizes:
             clean, after = bb.vlmo_predict(lc[:, :k]), bb.vlmo_predict(la[:, :k])
             top = la[:, :k].topk(2).values
             table[k] = (clean, after, (top[:, 0] - top[:, 1]).tolist())
     else:
-        for k in CANDIDATE_SIZES:
+        for k in sizes:
             if k > 128:
                 continue
             _, black_k, _, _, _ = tsb.build(flavor, "base", n_answers=k, k_test=min(128, k))
