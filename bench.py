@@ -502,7 +502,11 @@ def main():
 
     from vqattack_amd.attack.asr import SuccessLedger
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox import tuned_gemms
 
+    # recorded hipBLASLt solutions for the white boxes' fp32 GEMMs (read-only TunableOp; library defaults when the tracked
+    # file is absent or was recorded for another software stack) -- VQA_TUNED_GEMMS=off disables it
+    gemms_tuned = tuned_gemms.enable()
     cfg = make_config(args)
     flavor, white, black, adapters, text_len = build_models(args, cfg, device)
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
@@ -588,6 +592,8 @@ def main():
                        "mean_real_tokens": round(sum(n_words) / len(n_words) + 2, 2), "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
+            "tuned_gemms": ({"file": os.path.relpath(os.environ.get("VQA_TUNED_GEMMS", tuned_gemms.DEFAULT_FILE), ROOT),
+                             **tuned_gemms.status()} if gemms_tuned else None),
             "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
                             "tensor_device": str(coll_device), "calls": ledger.collectives}
                            if use_dist else None),
