@@ -1,19 +1,31 @@
 #!/bin/bash
-# Record the fastest hipBLASLt solution for every GEMM shape of a bench workload (PyTorch TunableOp, tuning ON), then A/B
-# the recorded file against the library defaults on the same box.   usage: tools/tune_gemms.sh <out_dir> [bench.py args...]
+# Record the fastest library solution (hipBLASLt / rocBLAS) for every GEMM shape of the bench workloads (PyTorch TunableOp,
+# tuning ON), merge the per-workload results, then A/B the merged file against the library defaults on the same box.
+#   usage: [TUNE_SET="default albef large"] [AB=1] tools/tune_gemms.sh <out_dir>      (raw_*.csv of earlier calls are merged too)
 # The CSV to track is <out_dir>/tunableop_mi355x_rocm72.csv (copy it to vqattack_amd/tuning/).
 set -e -o pipefail
-out=$1; shift
+out=$1
 mkdir -p "$out"
-csv="$out/tunableop_mi355x_rocm72.csv"
-rm -f "$csv"
-PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME="$csv" PYTORCH_TUNABLEOP_VERBOSE=0 \
-  PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=40 VQA_TUNED_GEMMS=off \
-  python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-b256 "$@" > "$out/tuning_run.json" 2> "$out/tuning_run.err"
-ls -la "$out"
-wc -l "$csv"
+tune() {   # tag, bench args...
+  tag=$1; shift
+  rm -f "$out/raw_${tag}"*.csv
+  PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME="$out/raw_${tag}.csv" \
+    PYTORCH_TUNABLEOP_VERBOSE=0 PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=40 VQA_TUNED_GEMMS=off \
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-b256 "$@" > "$out/tuning_${tag}.json" 2> "$out/tuning_${tag}.err"
+  ls "$out"/raw_${tag}*.csv
+}
+for w in ${TUNE_SET:-default albef large}; do
+  case $w in
+    default) tune default ;;
+    albef) tune albef_b256 --model albef_base --batch 256 --pgd-steps 4 ;;
+    large) tune vlmo_large_joint --model vlmo_large --batch 128 --joint 8 --pgd-steps 9 ;;
+  esac
+done
+python3 tools/merge_tunable.py "$out/tunableop_mi355x_rocm72.csv" "$out"/raw_*.csv
+wc -l "$out/tunableop_mi355x_rocm72.csv"
+[ "${AB:-1}" = "1" ] || exit 0
 for i in 1 2; do
-  VQA_TUNED_GEMMS=off python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b256 "$@" > "$out/ab_default_$i.json" 2> "$out/ab_default_$i.err"
-  VQA_TUNED_GEMMS="$csv" python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b256 "$@" > "$out/ab_tuned_$i.json" 2> "$out/ab_tuned_$i.err"
+  VQA_TUNED_GEMMS=off python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b256 > "$out/ab_default_$i.json" 2> "$out/ab_default_$i.err"
+  VQA_TUNED_GEMMS="$out/tunableop_mi355x_rocm72.csv" python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b256 > "$out/ab_tuned_$i.json" 2> "$out/ab_tuned_$i.err"
 done
 for f in "$out"/ab_*.json; do echo "$f $(python3 -c "import json,sys; r=json.load(open('$f')); print(r['value'], r.get('tuned_gemms'))")"; done

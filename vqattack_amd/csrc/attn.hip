@@ -115,6 +115,15 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kLazyMax = 8.0f;
 constexpr int kVi = 66;                 // LDS row stride of the interleaved V tile: conflict-free stores and b64 reads
+// A 32 x 128 fp32 tile staged through LDS (the saved scores in the dK / dV kernel, dS^T in the dQ kernel): fetched with four
+// 16-byte loads per thread (thread t: row t / 32 + 8 j, columns 4 (t % 32) ..), a tile ahead; read back one value per
+// lane.  Row stride 136 floats: the two lane halves read rows 4 apart, 4 * 136 = 32 mod 64 banks -> conflict-free.
+constexpr int kDsStride = 136;
+
+struct DsRegs {
+  f32x4 v[4];
+};
+
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -447,11 +456,6 @@ __global__ __launch_bounds__(kBlock) void attn_delta_kernel(const float* __restr
 // (row stride 136 floats: the two lane halves read rows 4 apart, 4 * 136 = 32 mod 64 banks -> conflict-free), and every
 // lane reads its 16 B-operand values back with ds_read_b32.  Same products in the same order: results are bitwise those
 // of the direct form.
-constexpr int kDsStride = 136;
-
-struct DsRegs {
-  f32x4 v[4];
-};
 
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const float* __restrict__ k,
                                                                        const float* __restrict__ ds,
@@ -634,6 +638,10 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   __shared__ __attribute__((aligned(16))) float Qbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Gbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
+  // FROM_SCORES: the saved-score tile (32 queries x this block's 128 keys) goes through LDS, fetched a tile ahead with
+  // 16-byte loads -- round 3 read it with 16 dword loads per lane issued right before the dP chain, whose 32 MFMAs
+  // (~0.85 us) do not cover an HBM access under load
+  __shared__ __attribute__((aligned(16))) float Sbuf[FROM_SCORES ? 2 : 1][FROM_SCORES ? kTile * kDsStride : 4];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
   const BlockCoord bc = block_coord((d.Sk + 127) / 128, d.B, d.H);
@@ -695,12 +703,31 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     }
     return t;
   };
+  // staging role of this thread for the score tile: query row (t / 32) + 8 j, keys K0 + 4 (t % 32) .. + 3
+  const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
+  const bool scol_ok = FROM_SCORES && bc.blk * 128 + scol < sc_pitch(d.Sk);     // the last key block may pass the pitch
+  const float* ssp = FROM_SCORES ? bslab + (scol_ok ? bc.blk * 128 + scol : 0) : nullptr;
+  auto load_scores = [&](int q0) {
+    DsRegs t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                // rows beyond Sq are clamped (their P is 0 whatever is read)
+      const int qq = q0 + srow + 8 * j;
+      t.v[j] = __builtin_nontemporal_load(
+          reinterpret_cast<const f32x4*>(ssp + static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * init_sr));
+    }
+    return t;
+  };
+  auto store_scores = [&](float* buf, const DsRegs& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
+  };
   f32x16 bcur = {0};
   if (kInit && !FROM_SCORES && active) bcur = load_bias(0);
   {
     const TileRegs tq = load_tile_clamped(qb, d.q_ss, 0, d.Sq), tg = load_tile_clamped(gb, go_ss, 0, d.Sq);
     float rl, rd;
     row_consts(0, rl, rd);
+    if (FROM_SCORES) store_scores(Sbuf[0], load_scores(0));
     store_tile_interleaved(Qbuf[0], tq, d.scale);
     store_tile_interleaved(Gbuf[0], tg, 1.0f);
     if (threadIdx.x < kTile) {
@@ -719,21 +746,25 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     const float* Ds = Dbuf[qt & 1] + 4 * h;
     const bool more = qt + 1 < n_tiles;
     TileRegs tq, tg;
+    DsRegs ts;
     float rl = 0.0f, rd = 0.0f;
     if (more) {
       tq = load_tile_clamped(qb, d.q_ss, q0 + kTile, d.Sq);
       tg = load_tile_clamped(gb, go_ss, q0 + kTile, d.Sq);
+      if (FROM_SCORES) ts = load_scores(q0 + kTile);
       row_consts(q0 + kTile, rl, rd);
     }
     if (active) {
       f32x16 bnext = {0};
-      if (FROM_SCORES) bcur = load_bias(q0);     // needed only after the dP chain below: no tile-ahead prefetch, 16
-      else if (kInit && more) bnext = load_bias(q0 + kTile);                                   // registers fewer
+      if (!FROM_SCORES && kInit && more) bnext = load_bias(q0 + kTile);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 st = bcur, dp = {0};
       if (FROM_SCORES) {
 #pragma unroll
         for (int s = 0; s < 32; ++s) dp = mfma(Gr[2 * s], vf[s], dp);
+        const float* Sc = Sbuf[qt & 1] + 4 * h * kDsStride + wave * kTile + r;   // S[query rowi][this lane's key]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = Sc[((i & 3) + 8 * (i >> 2)) * kDsStride];
       } else {
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
@@ -780,6 +811,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     if (more) {
       store_tile_interleaved(Qbuf[(qt + 1) & 1], tq, d.scale);
       store_tile_interleaved(Gbuf[(qt + 1) & 1], tg, 1.0f);
+      if (FROM_SCORES) store_scores(Sbuf[(qt + 1) & 1], ts);
       if (threadIdx.x < kTile) {
         Lbuf[(qt + 1) & 1][threadIdx.x] = rl;
         Dbuf[(qt + 1) & 1][threadIdx.x] = rd;
