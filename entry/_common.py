@@ -27,6 +27,8 @@ def init_distributed():
     # all-gather as on 8 GPUs (run_sweep(force_collective=dist.is_initialized()))
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from vqattack_amd.whitebox import tuned_gemms
+    tuned_gemms.enable()       # recorded library GEMM solutions for the white boxes (read-only; defaults when absent)
     return rank, world, torch.device("cuda", local)
 
 
