@@ -341,7 +341,7 @@ def attention_traffic(batch, heads, seq, with_bias):
     this shape), per kernel."""
     shape = dict(op="attention", batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias))
     parts = {k: recorded_traffic(k, shape)[0] for k in ("attn_fwd_kernel", "attn_delta_kernel", "attn_bwd_dkv_kernel",
-                                                        "attn_bwd_dq_from_ds_kernel")}
+                                                        "attn_bwd_dq_staged_kernel")}
     if any(v is None for v in parts.values()):
         return dict(traffic=None, traffic_source=PMC_TRAFFIC, traffic_shape=shape)
     return dict(traffic=sum(parts.values()), traffic_kind="recorded", traffic_per_kernel=parts, traffic_shape=shape,
@@ -351,7 +351,7 @@ def attention_traffic(batch, heads, seq, with_bias):
 def attention_microbench(batch, heads, seq, with_bias, reps=10):
     """The white box's fp32 MFMA attention (csrc/attn.hip) at the attack's shape: `reps` back-to-back forward launches
     (saving the scores, as a differentiated forward does) and `reps` backward calls (delta pre-pass, dK / dV kernel that
-    starts from the saved scores and stores dS^T, dQ-from-dS^T kernel), one event pair around each group.  Flops are the algorithm's (2 S^2 d per matrix product and (batch, head): 2 products forward, 5
+    starts from the saved scores and stores dS^T, dQ-from-dS^T kernel staged through LDS), one event pair around each group.  Flops are the algorithm's (2 S^2 d per matrix product and (batch, head): 2 products forward, 5
     backward -- the usual flash-attention accounting), against the dense fp32 matrix peak of v_mfma_f32_32x32x2_f32."""
     from vqattack_amd import attention
     gen = torch.Generator(device="cuda").manual_seed(2)
@@ -392,7 +392,7 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
     tf_f, tf_b = 2 * product / ms_f / 1e9, 4 * product / ms_b / 1e9
     tf = 6 * product / (ms_f + ms_b) / 1e9
     return dict(kernel="vqa_attn_fwd + vqa_attn_bwd (attn_fwd_kernel; attn_delta_kernel, attn_bwd_dkv_kernel, "
-                       "attn_bwd_dq_from_ds_kernel)",
+                       "attn_bwd_dq_staged_kernel)",
                 bound="mfma", achieved=round(tf, 1), peak=FP32_MFMA_PEAK_TFS, unit="TFLOP/s",
                 frac=round(tf / FP32_MFMA_PEAK_TFS, 4), **attention_traffic(batch, heads, seq, with_bias),
                 shape=dict(batch=batch, heads=heads, seq=seq, head_dim=64, bias=bool(with_bias)),
