@@ -14,7 +14,9 @@ dev = "cuda:0"
 cfg = vlmo_base(384)
 model = FrozenVlmo(cfg, seed=0).to(dev)
 ad = VlmoAttackAdapters(model)
-for batch in (1, 4, 16):
+fused_modes = [True, False] if os.environ.get("AB_FUSED", "1") == "1" else [True]
+for fused, batch in [(f, b) for f in fused_modes for b in (1, 4, 16)]:
+    model.fused_blocks = fused          # False: the eager nn.Module block loop (autograd), round 3's path
     ids = torch.zeros(batch, 40, dtype=torch.long, device=dev)
     ids[:, 0], ids[:, 1:9], ids[:, 9] = 101, 2054, 102
     ad.set_text(ids, (ids != 0).long())
@@ -30,5 +32,5 @@ for batch in (1, 4, 16):
                                                         sanity_checks=False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print("batch %2d  graph=%-5s  %.2f ms/iteration  %.2f examples/s" % (batch, graph, dt / 40 * 1e3, batch / dt),
-              flush=True)
+        print("%-14s batch %2d  graph=%-5s  %.2f ms/iteration  %.2f examples/s" % (
+            "fused blocks" if fused else "eager blocks", batch, graph, dt / 40 * 1e3, batch / dt), flush=True)

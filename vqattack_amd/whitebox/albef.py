@@ -8,6 +8,7 @@ the image states in layers >= ``fusion_layer`` = 6; 13 hidden states; MLM head) 
 
 PyTorch-ROCm plumbing, not the product: the product is what happens between two calls of these closures.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -163,7 +164,7 @@ class FrozenAlbef(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         # the ViT (577 of the <= 617 tokens of a pair) runs on whitebox/_fused.py on the GPU; see FrozenVlmo
-        self.fused_blocks = True
+        self.fused_blocks = os.environ.get("VQA_FUSED_BLOCKS", "1") != "0"
         self._fused_spec = None
 
     def _apply(self, fn, *args, **kwargs):

@@ -15,6 +15,7 @@ Differences from the reference that serve the MI355X design (none changes a sing
   * attention is the exact-fp32 MFMA kernel of ``csrc/attn.hip`` (``_mha.py``) on the packed qkv projection, with the
     relative-position bias and key-padding mask folded into one additive mask.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -175,7 +176,7 @@ class FrozenVlmo(nn.Module):
         # On the GPU the block loop runs without an autograd graph inside (library GEMMs + csrc/attn.hip + the fused
         # block glue of csrc/block.hip, whitebox/_fused.py) when the shapes are the hand-written kernels' (head size 64:
         # every BASELINE configuration); False keeps the eager nn.Module loop (parity tests compare the two).
-        self.fused_blocks = True
+        self.fused_blocks = os.environ.get("VQA_FUSED_BLOCKS", "1") != "0"      # "0": A/B measurements of the eager loop
         self._fused_spec = None
 
     def _apply(self, fn, *args, **kwargs):
