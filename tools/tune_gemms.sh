@@ -9,6 +9,8 @@ mkdir -p "$out"
 tune() {   # tag, bench args...
   tag=$1; shift
   rm -f "$out/raw_${tag}"*.csv
+  # RESUME=<tracked.csv>: start from already recorded shapes (TunableOp reads the file first and tunes only what is missing)
+  [ -n "$RESUME" ] && cp "$RESUME" "$out/raw_${tag}0.csv"
   PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME="$out/raw_${tag}.csv" \
     PYTORCH_TUNABLEOP_VERBOSE=0 PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=40 VQA_TUNED_GEMMS=off \
     python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-b256 "$@" > "$out/tuning_${tag}.json" 2> "$out/tuning_${tag}.err"

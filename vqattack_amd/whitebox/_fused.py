@@ -239,6 +239,9 @@ class _Encoder(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, call):
+        # an output the loss does not touch (every feature map during an MLM step of the dual loss) must reach backward
+        # as None, not as a materialised zero tensor: 12 x (fill + read) of (B, S, D) per step otherwise
+        ctx.set_materialize_grads(False)
         save = ctx.needs_input_grad[0]
         feats, states, saved = _forward(x0.detach(), call, save)
         if save:
