@@ -440,3 +440,44 @@ def test_mixed_batch_of_only_dual_samples_equals_the_bucket_path_and_the_oracle(
                 ts.encode_words = orig
         assert mixed.adv_text_ids[s, :n].cpu().tolist() == new_ids[0].tolist(), (flavor, s)
         assert (mixed.adv_images[s].cpu() == adv[0]).float().mean().item() >= 0.99, (flavor, s)
+
+
+def test_vlmo_mixed_loss_on_a_ragged_batch_matches_per_sample_oracle():
+    """The VLMO copy's third loss (``ls`` not in {0, 1}: feature loss / (layers * Ntok) + 0.1 * CE(labels) + 0.1 * sum of
+    CE(synonym label sets), ``VLMO_VQAttack/cleverhans/.../fast_gradient_method.py:127-131``; not reached by the
+    reference's drivers) on a BATCH of three questions of different lengths: every sample is weighted by its own token
+    count and its own label counts, so each sample's FGM step equals the batch-1 oracle's, and the reported loss is the
+    sum of the three batch-1 losses."""
+    import numpy as np
+    from oracle import cleverhans_cpu as o
+    from vqattack_amd import attacks
+    cpu_model, gpu_model, adapters_cls, ref_cls, cfg = _build("vlmo")
+    g = torch.Generator().manual_seed(51)
+    images = torch.empty(3, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g)
+    start = torch.clamp(images + torch.empty_like(images).uniform_(-0.1, 0.1, generator=g), -1, 1)
+    masks = (IDS != 0).long()
+    labels = torch.full_like(IDS, -100)
+    labels[0, 2], labels[1, 3], labels[1, 4], labels[2, 1] = 2003, 2024, 2051, 2054
+    syn = [torch.full_like(IDS, -100), torch.full_like(IDS, -100)]
+    syn[0][0, 2], syn[0][1, 3], syn[0][2, 1] = 2004, 2025, 2055
+    syn[1][0, 3], syn[1][1, 4], syn[1][2, 2] = 2061, 2052, 2060   # (a set without any label of a sample is NaN in the
+    #                                                               reference's batch-1 F.cross_entropy: not a case)
+    ad = adapters_cls(gpu_model)
+    ad.set_text(IDS.to(DEV), masks.to(DEV))
+    ad.set_mlm_rows(None)
+    targets = ad.gen_ori_feats(images.to(DEV))
+    y = [labels.to(DEV), targets[1], targets[2], [[s.to(DEV)] for s in syn]]
+    adv, loss = attacks.fast_gradient_method(ad.pgd_mlm_attack, start.to(DEV), 0.01, np.inf, images.to(DEV), clip_min=-1,
+                                             clip_max=1, y=y, ls=2, flavor="vlmo", sanity_checks=True)
+    want_loss = 0.0
+    for s in range(3):
+        ref = ref_cls(cpu_model, IDS[s:s + 1], masks[s:s + 1])
+        t = ref.gen_ori_feats(images[s:s + 1])
+        ys = [labels[s:s + 1], t[1], t[2], [[x[s:s + 1]] for x in syn]]
+        with torch.enable_grad():
+            want, ls_s = o.fast_gradient_method(ref.pgd_mlm_attack, start[s:s + 1], 0.01, np.inf, images[s:s + 1],
+                                                clip_min=-1, clip_max=1, y=ys, ls=2, flavor="vlmo")
+        want_loss += float(ls_s)
+        same = (adv[s].cpu() == want[0].detach()).float().mean().item()
+        assert same >= 0.99, (s, same)
+    assert abs(float(loss) - want_loss) <= 2e-4 * abs(want_loss)

@@ -226,10 +226,8 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
             # mixed loss, V: fast_gradient_method.py:127-131 (no truncation in this branch): feature loss / (13*Ntok)
             # + 0.1 * CE(labels) + 0.1 * sum over synonym label sets -- all CE terms in ONE fused launch
             if isinstance(out[2], LayerFeatures) and out[2].layers[0].shape[0] > 1:
-                # the three terms are weighted per SAMPLE in the reference (batch 1: 1/(13*Ntok) with that sample's
-                # token count, CE means over that sample's labels); with several samples in one LayerFeatures batch the
-                # ratios would differ per sample and change sign(grad).  The reference's drivers never reach this branch.
-                raise ValueError("the VLMO mixed loss (ls not in {0, 1}) is defined for batch-1 model outputs only")
+                _vlmo_mixed_batched(out, y, slot, leaves, sign, flag, ws)
+                return
             sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
             scale = 1.0 / (out[2].shape[0] * out[2].shape[1])
             pairs = [(out[2], y[2])] if out[1] is None else [(out[1], y[1]), (out[2], y[2])]
@@ -238,6 +236,38 @@ def _loss_and_grad(model_fn, leaves, model_in, y, ls, flavor, targeted, slot, bk
                                                               accumulate=True, flag=flag, ws=ws))
         else:
             raise UnboundLocalError("loss is undefined for ls={!r} (as in the reference)".format(ls))
+
+
+def _vlmo_mixed_batched(out, y, slot, leaves, sign, flag, ws):
+    """The VLMO mixed loss (``ls`` not in {0, 1}; V: fast_gradient_method.py:127-131 -- never reached by the reference's
+    drivers) for a BATCHED ``LayerFeatures`` output.  The reference weighs the three terms per sample (batch 1):
+    ``feature loss / (layers * Ntok)`` with that sample's own token count, ``0.1 * CE`` means over that sample's labels.
+    Per sample b of the batch: the feature gradient comes from the usual ONE launch over all maps and is then scaled by
+    ``1 / (layers * Ntok_b)`` row-block by row-block; the loss value is accumulated by one small loss-only launch per
+    sample; the cross-entropy terms are normalised per sample (``rows_per_sample``).  A rare path: written for
+    correctness, not for speed."""
+    lf, tgt = out[2], y[2]
+    if not isinstance(tgt, LayerFeatures):
+        raise ValueError("the batched VLMO mixed loss takes LayerFeatures targets")
+    layers = [t if t.dtype == torch.float32 else t.to(torch.float32) for t in lf.layers]
+    targets = [t.detach() for t in tgt.layers]
+    b, n = layers[0].shape[0], layers[0].shape[1]
+    w = lf.row_weight if lf.row_weight is not None else tgt.row_weight
+    ntok = [n] * b if w is None else [int(v) for v in (w != 0).sum(dim=1).tolist()]       # one host read (rare path)
+    scales = [1.0 / (len(layers) * max(v, 1)) for v in ntok]
+    scale = torch.tensor(scales, dtype=torch.float32, device=layers[0].device)
+    grads = ops.neg_cos_rows_multi([t.detach() for t in layers], targets, None, accumulate=False, gscale=sign,
+                                   want_grad=True, row_weight=w, weight_period=b if w is not None else 1, ws=ws)
+    for g in grads:
+        g.mul_(scale.view(b, 1, 1))
+    for s in range(b):                                   # the loss VALUE: sum_b scale_b * (feature loss of sample b)
+        ops.neg_cos_rows_multi([t[s:s + 1].detach() for t in layers], [t[s:s + 1] for t in targets], slot.word,
+                               accumulate=s > 0, gscale=sign * scales[s], want_grad=False,
+                               row_weight=None if w is None else w[s:s + 1].contiguous(), weight_period=1)
+    sets = torch.cat([y[0].reshape(1, -1)] + [syn[0].reshape(1, -1) for syn in y[3]], dim=0)
+    more_t, more_g = _ce_backward(out[0], sets, slot, leaves, sign, scale=0.1, accumulate=True, flag=flag, ws=ws,
+                                  per_sample=True)
+    torch.autograd.backward(list(layers) + more_t, list(grads) + more_g, inputs=leaves)
 
 
 def _mixed_loss_and_grad(model_fn, leaves, model_in, y, flavor, slot, mlm_labels=None, ws=None, flag=None):
