@@ -97,6 +97,41 @@ elif phase == "attn":
         assert scores is not None
         attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], 0.125,
                             scores=scores)
+elif phase in ("ln_fwd", "ln_bwd", "gelu"):
+    # the white box's block glue (csrc/block.hip) at the bench layout: 64 x 591 tokens x 768, image-expert hidden 3072
+    b, s, d = 64, bench_text_layout()[0] + 577, 768
+    t, rows = s - 577, 64 * (bench_text_layout()[0] + 577)
+    dev = "cuda"
+    if phase == "gelu":
+        n = b * 577 * 3072
+        h, da = torch.randn(n, device=dev), torch.randn(n, device=dev)
+        a = torch.empty_like(h)
+        shape_record = dict(op="gelu_fwd+gelu_bwd", elements=n)
+        for _ in range(3):
+            ops.gelu_fwd(h, out=a)
+            ops.gelu_bwd(h, da)
+    else:
+        x, r = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
+        gam, bet, sc = torch.ones(d, device=dev), torch.zeros(d, device=dev), torch.ones(d, device=dev)
+        mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        x_out = torch.empty(rows, d, device=dev)
+        y0, y1 = torch.empty(b * t, d, device=dev), torch.empty(b * (s - t), d, device=dev)
+        ops.ln_fwd(x, gam, bet, y0, mean, rstd, 1e-6, r0=r, rscale=sc, x_out=x_out, gamma1=gam, beta1=bet, y1=y1,
+                   period=s, split=t)
+        if phase == "ln_fwd":     # residual add + text / image LayerNorm + split: read x, r; write x_out, y = 16 B/element
+            shape_record = dict(op="ln_fwd", rows=rows, dim=d, residual=True, split=True)
+            for _ in range(3):
+                ops.ln_fwd(x, gam, bet, y0, mean, rstd, 1e-6, r0=r, rscale=sc, x_out=x_out, gamma1=gam, beta1=bet, y1=y1,
+                           period=s, split=t)
+        else:                     # LN backward + residual + loss gradient + split branch gradient: 24 B/element
+            dy0, dy1 = torch.randn_like(y0), torch.randn_like(y1)
+            g_a, g_inj = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
+            dx = torch.empty(rows, d, device=dev)
+            dr0, dr1 = torch.empty_like(y0), torch.empty_like(y1)
+            shape_record = dict(op="ln_bwd", rows=rows, dim=d, residual=True, injected=True, split=True)
+            for _ in range(3):
+                ops.ln_bwd(dy0, x_out, mean, rstd, gam, dx, dy1=dy1, gamma1=gam, g_a=g_a, g_inj=g_inj, rscale=sc, dr0=dr0,
+                           dr1=dr1, period=s, split=t)
 elif phase == "sumsq":
     g = torch.randn(64, 3, 384, 384, device="cuda")
     shape_record = dict(op="sumsq_per_sample", batch=64, elements=g.numel())
