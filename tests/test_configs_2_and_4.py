@@ -147,3 +147,81 @@ def test_bench_runs_the_two_configurations_at_full_batch(argv, model, capsys, mo
     assert rec["roofline_loss"]["launches"] >= 2 and 0 < rec["roofline_loss"]["frac"] < 1
     assert rec["roofline_attention"]["bound"] == "mfma"
     torch.cuda.empty_cache()
+
+
+def test_vlmo_large_full_budget_joint_attack_matches_cpu_oracle():
+    """configs[4] at the reference's FULL budget: VLMO-large (24 x 1024, 25 maps per loss launch), joint image + text attack
+    with 2 substitutable words -- blocks [12, 12, 16] + 2 probe steps = 42 white-box gradient steps -- against the batch-1
+    CPU oracle loop (``vlmo_module.py:1943-2055``).  Tolerances of a complete attack (tests/test_fullsize_parity.py)."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import VlmoRefAdapters
+    from tests.test_fullsize_parity import _compare, _cpu_threads, _inputs
+    from vqattack_amd.attack import text_update
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_large
+    budget, words = 40, 2
+    before = torch.get_num_threads()
+    torch.set_num_threads(_cpu_threads())
+    try:
+        cpu_model = FrozenVlmo(vlmo_large(384), seed=0)
+        gpu_model = copy.deepcopy(cpu_model).to(DEV)
+        ids, masks, img, eta = _inputs([7], 40, seed=9)
+        att = torch.zeros_like(ids, dtype=torch.bool)
+        att[:, 2:2 + words] = True
+        adapters = VlmoAttackAdapters(gpu_model)
+        proposals = text_update.propose_candidates(adapters.mlm_logits(ids.to(DEV), masks.to(DEV)), ids, att, threshold=0)
+        sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
+        attack = BatchedVQAttack(adapters, "vlmo", gpu_model.embedding_tables(),
+                                 AttackConfig(budget=budget, sanity_checks=True, sim_threshold=0.3), similarity_fn=sim)
+        res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV), att.to(DEV), init_eta=eta.to(DEV),
+                                  proposals=proposals)
+        assert res.gradient_steps == budget + words
+        adv, new_ids, losses = attack_loop.attack_one(VlmoRefAdapters, cpu_model, "vlmo", img, ids, masks, proposals[0],
+                                                      sim, init_eta=eta, budget=budget, sim_threshold=0.3)
+    finally:
+        torch.set_num_threads(before)
+    assert res.adv_text_ids[0].cpu().tolist() == new_ids[0].tolist()
+    same = _compare(res.adv_images[0].cpu(), adv[0].detach(), budget + words, full_attack=True)
+    print("VLMO-large {} gradient steps: {:.3%} of the pixels bit-identical to the CPU oracle".format(budget + words, same))
+    for got, want in zip(res.loss_lists, losses):
+        np.testing.assert_allclose(got, want, rtol=2e-4)
+    del gpu_model, attack, adapters
+    torch.cuda.empty_cache()
+
+
+def test_albef_base_dual_loss_batch_matches_per_sample_oracle():
+    """configs[2]'s white box with the reference's ``old_alg == 0`` blocks at full size: ALBEF-base, batch 2, 4 dual
+    iterations (feature step without projection + MLM step through the real 30 522-word head on the fused text states,
+    ``adv_attack.py:130-140,614-619``; loop ``projected_gradient_descent.py:153-189`` with the ALBEF copy's ``y`` slicing
+    and ``bkp`` arguments), 2-d labels on one sample and 3-d labels (K = 2) on the other, against each sample's own
+    batch-1 oracle loop."""
+    from oracle import attack_loop
+    from oracle.adapters_ref import AlbefRefAdapters
+    from tests.test_fullsize_parity import _compare, _cpu_threads, _dual_tasks, _inputs, _sum_by_step
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_base
+    budget = 8
+    before = torch.get_num_threads()
+    torch.set_num_threads(_cpu_threads())
+    try:
+        cpu_model = FrozenAlbef(albef_base(384, mlm_probability=0.0), seed=0)
+        gpu_model = copy.deepcopy(cpu_model).to(DEV)
+        ids, masks, img, eta = _inputs([5, 7], 9, seed=12)
+        tasks, oracle_tasks = _dual_tasks("albef", ids, None)
+        attack = BatchedVQAttack(AlbefAttackAdapters(gpu_model), "albef", gpu_model.embedding_tables(),
+                                 AttackConfig(budget=budget, sanity_checks=True))
+        res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV),
+                                  torch.zeros_like(ids, dtype=torch.bool).to(DEV), init_eta=eta.to(DEV), dual=True,
+                                  tasks=tasks)
+        assert res.gradient_steps == budget and len(res.loss_lists[0]) == budget
+        per_sample = []
+        for s in range(2):
+            n = int(masks[s].sum())
+            adv, _, losses = attack_loop.attack_one(AlbefRefAdapters, cpu_model, "albef", img[s:s + 1], ids[s:s + 1, :n],
+                                                    masks[s:s + 1, :n], None, None, init_eta=eta[s:s + 1], budget=budget,
+                                                    task=oracle_tasks[s])
+            _compare(res.adv_images[s].cpu(), adv[0].detach(), budget, full_attack=False)
+            per_sample.append(losses[0])
+    finally:
+        torch.set_num_threads(before)
+    np.testing.assert_allclose(res.loss_lists[0], _sum_by_step(per_sample), rtol=2e-4)
