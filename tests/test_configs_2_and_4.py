@@ -183,8 +183,11 @@ def test_vlmo_large_full_budget_joint_attack_matches_cpu_oracle():
     assert res.adv_text_ids[0].cpu().tolist() == new_ids[0].tolist()
     same = _compare(res.adv_images[0].cpu(), adv[0].detach(), budget + words, full_attack=True)
     print("VLMO-large {} gradient steps: {:.3%} of the pixels bit-identical to the CPU oracle".format(budget + words, same))
+    # the loss runs from -549 through 0 to +623 over a block: relative to the trajectory's scale, not to the value that
+    # happens to be near the zero crossing (the two sign-PGD trajectories differ in 0.6 % of the pixels by then)
+    scale = max(abs(v) for block in losses for v in block)
     for got, want in zip(res.loss_lists, losses):
-        np.testing.assert_allclose(got, want, rtol=2e-4)
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * scale)
     del gpu_model, attack, adapters
     torch.cuda.empty_cache()
 
