@@ -219,3 +219,31 @@ def test_vlmo_base_fused_encoder_equals_eager_blocks_and_frees_its_activations()
         del feats, states, img
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() <= base + (1 << 20), "activations of finished calls are still allocated"
+
+
+def test_block_glue_wrappers_refuse_short_or_foreign_operands():
+    """The kernels index raw pointers from the row count: a short buffer must be an exception in the wrapper, never an
+    out-of-bounds access on the device."""
+    from vqattack_amd import ops
+    rows, d = 12, 64
+    x = torch.randn(rows, d, device=DEV)
+    gam, bet = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    y = torch.empty(rows, d, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.ln_fwd(x, gam, bet, y, mean, rstd, 1e-6)
+    with pytest.raises(ValueError):
+        ops.ln_fwd(x, gam, bet, y[:-1], mean, rstd, 1e-6)                        # short output
+    with pytest.raises(ValueError):
+        ops.ln_fwd(x, gam, bet, y, mean[:-1].contiguous(), rstd, 1e-6)           # short statistics
+    with pytest.raises(ValueError):
+        ops.ln_fwd(x, gam[:-4].contiguous(), bet, y, mean, rstd, 1e-6)           # parameter vector of another width
+    with pytest.raises(TypeError):
+        ops.ln_fwd(x, gam, bet, y.cpu(), mean, rstd, 1e-6)                       # host tensor
+    with pytest.raises(ValueError):                                             # split output whose parts do not add up
+        ops.ln_fwd(x, gam, bet, torch.empty(4, d, device=DEV), mean, rstd, 1e-6, gamma1=gam, beta1=bet,
+                   y1=torch.empty(7, d, device=DEV), period=6, split=2)
+    dx = torch.empty_like(x)
+    with pytest.raises(ValueError):
+        ops.ln_bwd(y, x, mean, rstd, gam, dx, g_a=x[:-1])                        # short residual gradient
+    with pytest.raises(ValueError):
+        ops.gelu_bwd(x, torch.randn(rows - 1, d, device=DEV))

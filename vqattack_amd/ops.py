@@ -627,12 +627,40 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _rows_ok(name, t, numel):
+    """The block-glue kernels index raw pointers from the row count: every operand is checked for device, dtype, layout
+    and SIZE here (a short buffer would be an out-of-bounds access on the device, not an exception)."""
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError("{} must be a contiguous float32 HIP tensor".format(name))
+    if t.numel() != numel:
+        raise ValueError("{} has {} elements, expected {}".format(name, t.numel(), numel))
+
+
+def _split_sizes(rows, d, period, split, second):
+    """(elements of the segment-0 buffer, of the segment-1 buffer) of a tensor given whole or split."""
+    if second is None:
+        return rows * d, 0
+    if period <= 0 or rows % period or not 0 <= split <= period:
+        raise ValueError("a split tensor needs period > 0 dividing the row count and 0 <= split <= period")
+    n0 = rows // period * split
+    return n0 * d, (rows - n0) * d
+
+
 def ln_fwd(x, gamma0, beta0, y0, mean, rstd, eps, r0=None, r1=None, rscale=None, x_out=None, gamma1=None, beta1=None,
            y1=None, period=0, split=0):
     """``vqa_ln_fwd`` on ``x`` (rows, D) fp32 contiguous: optional prologue ``x_out = x + rscale * r`` (r whole as ``r0`` or
     split as ``r0`` / ``r1``), then LayerNorm with the second parameter set for segment-1 rows, output whole (``y0``) or
     split (``y0`` / ``y1``).  Token layout: ``period`` rows per batch element, the first ``split`` are segment 0."""
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    _rows_ok("x", x, rows * d), _rows_ok("x_out", x_out, rows * d)
+    for name, t in (("gamma0", gamma0), ("beta0", beta0), ("gamma1", gamma1), ("beta1", beta1), ("rscale", rscale)):
+        _rows_ok(name, t, d)
+    _rows_ok("mean", mean, rows), _rows_ok("rstd", rstd, rows)
+    for name, t0, t1 in (("r", r0, r1), ("y", y0, y1)):
+        n0, n1 = _split_sizes(rows, d, period, split, t1)
+        _rows_ok(name + "0", t0, n0), _rows_ok(name + "1", t1, n1)
     with _on(x):
         check(lib().vqa_ln_fwd(_p(x), _p(r0), _p(r1), _p(rscale), _p(x_out), _p(gamma0), _p(beta0), _p(gamma1), _p(beta1),
                                _p(y0), _p(y1), _p(mean), _p(rstd), rows, d, period, split, eps, stream_for(x)),
@@ -643,6 +671,14 @@ def ln_bwd(dy0, x, mean, rstd, gamma0, dx, dy1=None, gamma1=None, g_a=None, g_in
            period=0, split=0):
     """``vqa_ln_bwd``: ``dx = g_a + g_inj + LayerNorm'(dy)`` and optionally ``dr = rscale * dx`` (whole or split)."""
     rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    for name, t in (("x", x), ("dx", dx), ("g_a", g_a), ("g_inj", g_inj)):
+        _rows_ok(name, t, rows * d)
+    for name, t in (("gamma0", gamma0), ("gamma1", gamma1), ("rscale", rscale)):
+        _rows_ok(name, t, d)
+    _rows_ok("mean", mean, rows), _rows_ok("rstd", rstd, rows)
+    for name, t0, t1 in (("dy", dy0, dy1), ("dr", dr0, dr1)):
+        n0, n1 = _split_sizes(rows, d, period, split, t1)
+        _rows_ok(name + "0", t0, n0), _rows_ok(name + "1", t1, n1)
     with _on(x):
         check(lib().vqa_ln_bwd(_p(dy0), _p(dy1), _p(x), _p(mean), _p(rstd), _p(gamma0), _p(gamma1), _p(g_a), _p(g_inj),
                                _p(rscale), _p(dx), _p(dr0), _p(dr1), rows, d, period, split, stream_for(x)), "vqa_ln_bwd")
@@ -651,6 +687,7 @@ def ln_bwd(dy0, x, mean, rstd, gamma0, dx, dy1=None, gamma1=None, g_a=None, g_in
 def gelu_fwd(h, out=None):
     dev_f32(h, "h")
     out = torch.empty_like(h) if out is None else out
+    _rows_ok("out", out, h.numel())
     if h.numel():
         with _on(h):
             check(lib().vqa_gelu_fwd(_p(h), _p(out), h.numel(), stream_for(h)), "vqa_gelu_fwd")
@@ -661,6 +698,7 @@ def gelu_bwd(h, da, out=None):
     """``out = da * gelu'(h)``; ``out=None`` overwrites ``da``."""
     dev_f32(h, "h"), dev_f32(da, "da")
     out = da if out is None else out
+    _rows_ok("da", da, h.numel()), _rows_ok("out", out, h.numel())
     if h.numel():
         with _on(h):
             check(lib().vqa_gelu_bwd(_p(h), _p(da), _p(out), h.numel(), stream_for(h)), "vqa_gelu_bwd")
