@@ -3,7 +3,7 @@
 ``tests/golden/asr_base_<flavor>.json`` holds what the CPU oracle (``oracle/attack_loop`` per-sample loop with the full
 40-step budget + ``oracle/blackbox_ref`` per-question scorers; reference: ``adv_attack.py:559-733``,
 ``vlmo_module.py:1892-2091``) produced in the build container for seeded samples at VLMO-base / ALBEF-base size, 384 px
-(``tests/golden/make_asr_fixture.py``: 200 / 64 samples, questions of 4..12 words with 0..4 substitutable words, every
+(``tests/golden/make_asr_fixture.py``: 200 + 300 VLMO / 64 ALBEF samples, questions of 4..12 words with 0..4 substitutable words, every
 4th sample dual-loss): the victim's clean answers, its answers to the adversarial pairs, the substituted token ids and
 the success bits.  Here ONLY the product runs -- the batched joint attack on the MI355X (``attack_mixed``: HIP
 operators, mixed schedules and loss modes in one batch) and the batched black-box scorer -- on the same regenerated
@@ -29,18 +29,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _fixture(flavor):
-    path = os.path.join(ROOT, "tests", "golden", "asr_base_{}.json".format(flavor))
+# (fixture file, flavor).  The first two are required; further sets (``asr_base_<flavor>_<tag>.json``: independent draws
+# with another seed -- other images, questions, schedules) are picked up when committed.
+import glob  # noqa: E402
+FIXTURES = [("asr_base_vlmo.json", "vlmo"), ("asr_base_albef.json", "albef")]
+FIXTURES += sorted((os.path.basename(p), os.path.basename(p).split("_")[2])
+                   for p in glob.glob(os.path.join(ROOT, "tests", "golden", "asr_base_*_*.json")))
+
+
+def _fixture(name, flavor):
+    path = os.path.join(ROOT, "tests", "golden", name)
     if not os.path.exists(path):
         pytest.fail("missing fixture {} (python tests/golden/make_asr_fixture.py --flavor {})".format(path, flavor))
-    return json.load(open(path))
+    rec = json.load(open(path))
+    assert rec["flavor"] == flavor
+    return rec
 
 
-@pytest.mark.parametrize("flavor", ["vlmo", "albef"])
-def test_base_size_success_bits_match_the_recorded_oracle(flavor):
+@pytest.mark.parametrize("name,flavor", FIXTURES, ids=[f[0][9:-5] for f in FIXTURES])
+def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
     from vqattack_amd.attack import text_update
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
-    rec = _fixture(flavor)
+    rec = _fixture(name, flavor)
     assert rec["size"] == "base" and 0.3 <= rec["oracle_asr"] <= 0.7, "the fixture must be informative"
     n, k = rec["n"], rec["n_answers"]
     dev = torch.device("cuda", 0)
