@@ -87,7 +87,24 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     log("--gpus {} without a launcher environment: starting {} ranks: {}".format(args.gpus, args.gpus, " ".join(cmd)))
-    return subprocess.call(cmd)
+    import signal
+    proc = subprocess.Popen(cmd)
+
+    def forward(signum, _frame):            # a caller that stops this process (timeout, ^C) stops the ranks too:
+        if proc.poll() is None:             # torch.distributed.run ends its workers on SIGTERM / SIGINT
+            proc.send_signal(signum)
+    previous = {s: signal.signal(s, forward) for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        return proc.wait()
+    finally:
+        for s, h in previous.items():
+            signal.signal(s, h)
+        if proc.poll() is None:             # leaving on an exception: no rank may outlive the launcher
+            proc.terminate()
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
 
 
 def dry_run(args, world, rank):
@@ -97,6 +114,9 @@ def dry_run(args, world, rank):
         dist.init_process_group("gloo")
     if int(os.environ.get("VQA_BENCH_FAIL_RANK", "-1")) == rank:
         raise SystemExit("rank {} fails on request (VQA_BENCH_FAIL_RANK)".format(rank))
+    if os.environ.get("VQA_BENCH_DRY_SLEEP"):            # test hook: ranks that are still busy when the launcher is stopped
+        log("rank {} pid {} sleeping".format(rank, os.getpid()))
+        time.sleep(float(os.environ["VQA_BENCH_DRY_SLEEP"]))
     ledger = SuccessLedger(world, rank, "cpu", force_collective=dist.is_initialized())
     mine = shard_indices(world * args.batch, rank, world)
     ledger.record(torch.tensor([i % 3 == 0 for i in mine]), sample_ids=mine)

@@ -64,3 +64,35 @@ def test_more_ranks_than_gpus_is_refused_for_rccl():
         return
     p = _run(["--gpus", "8", "--no-cpu-baseline"])
     assert p.returncode != 0 and "only" in p.stderr and not _json_lines(p.stdout)
+
+
+def test_stopping_the_launcher_stops_its_ranks():
+    """SIGTERM to ``python bench.py --gpus 2`` (a caller's timeout) reaches torch.distributed.run and both rank processes:
+    nothing of the run may stay behind holding a GPU."""
+    import re
+    import signal
+    import time
+    import psutil
+    e = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    e.update(OMP_NUM_THREADS="1", VQA_BENCH_DRY_SLEEP="120")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=e, stderr=subprocess.PIPE, text=True)
+    try:
+        pids, deadline = set(), time.time() + 240
+        while len(pids) < 2 and time.time() < deadline:          # both ranks are up and asleep
+            line = p.stderr.readline()
+            m = re.search(r"rank \d+ pid (\d+) sleeping", line)
+            if m:
+                pids.add(int(m.group(1)))
+        assert len(pids) == 2, "the ranks did not start"
+        family = psutil.Process(p.pid).children(recursive=True)
+        assert pids <= {c.pid for c in family}
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=60) != 0
+        gone, alive = psutil.wait_procs(family, timeout=30)
+        assert not alive, "left behind: {}".format([(c.pid, c.name()) for c in alive])
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for pid in pids:
+            if psutil.pid_exists(pid):
+                os.kill(pid, signal.SIGKILL)
