@@ -7,6 +7,8 @@ BASELINE.json names (VLMO-base / ALBEF-base, 384 px, the full 40-step budget), c
     python tests/golden/make_asr_fixture.py --flavor vlmo  --n 300 --seed 29 --out tests/golden/asr_base_vlmo_s29.json
     python tests/golden/make_asr_fixture.py --flavor albef --n 128 --seed 29 --sizes 8,12,16 \
         --out tests/golden/asr_base_albef_s29.json
+    python tests/golden/make_asr_fixture.py --flavor albef --n 96 --seed 31 --sizes 8,12,16 \
+        --out tests/golden/asr_base_albef_s31.json
 
 What is stored is data only: the seeds and shape parameters that regenerate the inputs (tests/test_success_bits.py
 ``make_samples``), the candidate proposals (host data injected on both sides), and the oracle pipeline's outputs -- the

@@ -3,7 +3,7 @@
 ``tests/golden/asr_base_<flavor>.json`` holds what the CPU oracle (``oracle/attack_loop`` per-sample loop with the full
 40-step budget + ``oracle/blackbox_ref`` per-question scorers; reference: ``adv_attack.py:559-733``,
 ``vlmo_module.py:1892-2091``) produced in the build container for seeded samples at VLMO-base / ALBEF-base size, 384 px
-(``tests/golden/make_asr_fixture.py``: 200 + 300 VLMO / 64 ALBEF samples, questions of 4..12 words with 0..4 substitutable words, every
+(``tests/golden/make_asr_fixture.py``: 200 + 300 VLMO / 64 + 128 + 96 ALBEF samples, questions of 4..12 words with 0..4 substitutable words, every
 4th sample dual-loss): the victim's clean answers, its answers to the adversarial pairs, the substituted token ids and
 the success bits.  Here ONLY the product runs -- the batched joint attack on the MI355X (``attack_mixed``: HIP
 operators, mixed schedules and loss modes in one batch) and the batched black-box scorer -- on the same regenerated
@@ -107,7 +107,8 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
 
 
 def test_pooled_success_rate_within_half_a_percent():
-    """north_star: attack-success rate within +-0.5 % of the reference's -- over every base-size sample of the sets above."""
+    """north_star: attack-success rate within +-0.5 % of the reference's -- per flavor and over every base-size sample of
+    the sets above."""
     missing = [f[0] for f in FIXTURES if f[0] not in RESULTS]
     if missing:
         pytest.skip("needs the per-set tests of this module to have run first (missing: {})".format(missing))
@@ -116,4 +117,5 @@ def test_pooled_success_rate_within_half_a_percent():
         n, want, got, diff = (sum(r[i] for r in rows) for i in (1, 2, 3, 4))
         print("{}: {} samples in {} sets, oracle ASR {:.4f}, product ASR {:.4f} (difference {:+.4f}), {} bits differ "
               "({:.2%})".format(flavor or "all", n, len(rows), want / n, got / n, (got - want) / n, diff, diff / n))
-    assert abs(got - want) / n <= 0.005 and diff / n <= 0.005      # the last pass of the loop: all sets pooled
+        # per flavor and pooled (a flavor with fewer than 200 samples could not resolve 0.5 %: one sample would be more)
+        assert n < 200 or (abs(got - want) / n <= 0.005 and diff / n <= 0.005), flavor

@@ -172,7 +172,7 @@ def test_batched_rank_answer_equals_reference_method(gold):
 def test_black_box_answers_equal_per_question_oracle(size):
     """Batched black-box scorers vs the per-question CPU oracle (oracle/blackbox_ref.py) on seeded samples: the answer
     indices that decide every attack-success bit must agree (32 samples).  At BASE size the same comparison is part of
-    tests/test_success_bits_base.py since round 4 -- the victim's clean and adversarial answers on 692 samples against the
+    tests/test_success_bits_base.py since round 4 -- the victim's clean and adversarial answers on 788 samples against the
     oracle scorers' recorded ones -- so the 4-sample base case that built four base-size models on the host here (40 s
     of the GPU box's CPU) is gone; ``size="base"`` still works when called by hand."""
     from oracle import blackbox_ref as bb
