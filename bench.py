@@ -40,8 +40,15 @@ FP32_MFMA_PEAK_TFS = 157.3  # dense fp32 matrix peak, v_mfma_f32_32x32x2_f32 (MI
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 2); with --sweep: timed passes over the whole fixed set (default 1)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed warm-up steps (default 1); with --sweep: untimed warm-up BATCHES per rank (default 1)")
+    ap.add_argument("--sweep", type=int, default=0, metavar="N_SAMPLES",
+                    help="BASELINE configs[3] as written: a FIXED seeded set of N_SAMPLES joint attacks (mixed schedules, "
+                         "every --dual-every-th sample dual-loss) sharded rank::world through attack/sweep.run_sweep -- "
+                         "strong scaling: examples/s = N_SAMPLES / max-over-ranks seconds")
+    ap.add_argument("--dual-every", type=int, default=4, help="with --sweep: every n-th sample is a dual-loss sample")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--pgd-steps", type=int, default=40)
     ap.add_argument("--image-size", type=int, default=384)
@@ -60,10 +67,49 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=40,
                     help="PGD steps of the CPU sample (default: one full 40-step example, ~10-15 s on 16 cores)")
     ap.add_argument("--no-b256", action="store_true")
+    ap.add_argument("--no-reference-style", action="store_true",
+                    help="skip the batch-1 leg that drives the drop-in with the reference's own packed closure")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only, runs without a GPU: the ranks rendezvous over gloo on the host, gather "
                          "stand-in success bits and rank 0 prints a line whose value is null (no measurement)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.sweep else 2
+    if args.warmup is None:
+        args.warmup = 1
+    return args
+
+
+def device_identity(index=None):
+    """A string that names the PHYSICAL device a rank computes on: the GPU's UUID where the runtime reports one, else
+    its PCI address.  Gathered over the ranks, the number of different strings is the number of GPUs that took part --
+    the evidence that an N-rank line was measured on N GPUs (``distinct_devices``)."""
+    if index is None or not torch.cuda.is_available():
+        import socket
+        return "host:{}".format(socket.gethostname())
+    prop = torch.cuda.get_device_properties(index)
+    uuid = getattr(prop, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return "uuid:{}".format(uuid)
+    return "pci:{:04x}:{:02x}:{:02x}".format(getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", index),
+                                             getattr(prop, "pci_device_id", 0))
+
+
+def gather_rank_records(record, identity, use_dist, coll_device):
+    """Every rank's (float record, device identity) on every rank: two small all-gathers OUTSIDE the timed region.
+    The identity travels as the two 63-bit halves of its SHA-1."""
+    import hashlib
+    h = hashlib.sha1(identity.encode()).digest()
+    ident = [int.from_bytes(h[:8], "big") >> 1, int.from_bytes(h[8:16], "big") >> 1]
+    if not use_dist:
+        return [list(record)], [tuple(ident)]
+    rec = torch.tensor(record, dtype=torch.float64, device=coll_device)
+    idt = torch.tensor(ident, dtype=torch.int64, device=coll_device)
+    recs = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    idts = [torch.empty_like(idt) for _ in range(dist.get_world_size())]
+    dist.all_gather(recs, rec)
+    dist.all_gather(idts, idt)
+    return [r.cpu().tolist() for r in recs], [tuple(i.cpu().tolist()) for i in idts]
 
 
 def free_port():
@@ -129,6 +175,102 @@ def dry_run(args, world, rank):
                                           "calls": ledger.collectives} if dist.is_initialized() else None)}),
               flush=True)
     if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _DryAttack:
+    """--dry-run stand-in of BatchedVQAttack for the sweep plumbing (shard -> batch -> ledger -> gathers) on the host:
+    no white box; a sample 'costs' its schedule's gradient steps, the first body token is marked as substituted."""
+
+    class cfg:
+        budget = 40
+
+    def attack_mixed(self, images, text_ids, text_masks, attackable, **_kw):
+        from vqattack_amd.attack.runner import BatchResult
+        from vqattack_amd.attack.schedule import gradient_steps
+        per = [gradient_steps(int(n), self.cfg.budget) for n in attackable.sum(dim=1).tolist()]
+        adv = text_ids.clone()
+        adv[:, 1] = -adv[:, 1]
+        return BatchResult(adv_images=images, adv_text_ids=adv, gradient_steps=sum(per), sample_steps=sum(per),
+                           global_steps=max(per))
+
+
+class _DryBlack:
+    """The stand-in victim changes its answer iff the ORIGINAL first body token is divisible by 3."""
+
+    def vqa_answer(self, images, text_ids, text_masks):
+        t = text_ids[:, 1]
+        return ((t < 0) & ((-t) % 3 == 0)).long()
+
+
+def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text_len, image_size, dry=False,
+               gemms_tuned=False):
+    """The ONE line of a --sweep run (rank 0).  ``records``: per rank [attack seconds, samples, batches, sample gradient
+    steps, white-box passes, gather seconds, dual-loss samples]."""
+    res = res_list[-1]
+    n = args.sweep
+    col = lambda j: [r[j] for r in records]                                  # noqa: E731
+    seconds, n_local, n_batches, s_steps, g_steps, gather, n_dual = (col(j) for j in range(7))
+    distinct = len(set(idents))
+    return {
+        "metric": "adversarial_vqa_examples_per_sec", "value": None if dry else round(n * args.steps / dt, 4),
+        "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None if dry else round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "{} VQAttack sweep (BASELINE configs[3]{}): a FIXED seeded set of {} (image, question) pairs "
+                               "sharded rank::world over {} rank(s), joint image+text attack with each sample's own block "
+                               "schedule (40 image steps + one probe per substitutable word, 4..12 words), every {}th "
+                               "sample dual-loss, mixed batches of <= {} per rank sorted by schedule length, {}x{} images, "
+                               "black-box scoring, ONE all-gather of success bits + ONE of the adversarial text; one step "
+                               "= one pass over the whole set".format(
+                                   args.model, "" if (args.model == "vlmo_base" and n >= 5000 and image_size == 384
+                                                      and args.pgd_steps == 40) else " shape, reduced",
+                                   n, world, args.dual_every, args.batch, image_size, image_size),
+                   "n_samples": n, "batch_per_gpu": args.batch, "pgd_steps": args.pgd_steps, "image_size": image_size,
+                   "text_len": text_len, "dual_every": args.dual_every,
+                   "sharding": "rank::world (DistributedSampler(shuffle=False), multitask_datamodule.py:54)"},
+        "dry_run": dry, "attack_success_rate": res["asr"], "distinct_devices": distinct,
+        "per_rank": {"seconds_attack": [round(v, 3) for v in seconds], "samples": [int(v) for v in n_local],
+                     "dual_loss_samples": [int(v) for v in n_dual],
+                     "n_batches": [int(v) for v in n_batches], "sample_steps": [int(v) for v in s_steps],
+                     "white_box_passes": [int(v) for v in g_steps],
+                     "gather_seconds": [round(v, 4) for v in gather]},
+        "imbalance": {"seconds_attack_min": round(min(seconds), 3), "seconds_attack_max": round(max(seconds), 3),
+                      "sample_steps_min": int(min(s_steps)), "sample_steps_max": int(max(s_steps)),
+                      "white_box_passes_min": int(min(g_steps)), "white_box_passes_max": int(max(g_steps)),
+                      "note": "a rank's gather_seconds includes its wait for the slowest rank; the collective's own "
+                              "latency is the minimum over ranks"},
+        "all_gather_latency_ms": round(min(gather) * 1e3, 3),
+        "tuned_gemms": gemms_tuned,
+        "collective": ({"backend": backend, "world": world, "calls": res["collectives"]} if backend else None),
+    }
+
+
+def check_distinct(idents, world, backend):
+    if backend == "nccl" and len(set(idents)) != world:
+        raise SystemExit("bench.py: {} ranks ran on {} distinct GPU(s): refusing to print an N-GPU line".format(
+            world, len(set(idents))))
+
+
+def dry_run_sweep(args, world, rank):
+    """--sweep --dry-run: the strong-scaling plumbing on the host (gloo): fixed set, rank::world shards, mixed batches,
+    success bits and adversarial text gathered, per-rank records gathered, one line from rank 0 (value null)."""
+    from vqattack_amd.attack.sweep import run_sweep
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+    torch.set_num_threads(1)
+    res = run_sweep("vlmo", None, _DryBlack(), None, n_samples=args.sweep, batch=args.batch, image_size=8, text_len=40,
+                    device="cpu", rank=rank, world=world, log_every=0, dual_every=args.dual_every, mixed=True,
+                    attack=_DryAttack(), force_collective=use_dist)
+    record = [res["seconds"], res["n_local"], res["n_batches"], res["gradient_steps"], res["global_steps"],
+              res["gather_seconds"], res["n_dual_local"]]
+    records, idents = gather_rank_records(record, device_identity(None), use_dist, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps(sweep_line(args, world, [res], 1.0, records, idents, "gloo" if use_dist else None, "vlmo", 40, 8,
+                                    dry=True)), flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -332,10 +474,8 @@ def stream_probe(nbytes=452984832, reps=12):
     the 8 TB/s spec the fractions are priced against and the guide's measured float4 copy (6.29 TB/s)."""
     import ctypes
     path = os.path.join(ROOT, "tools", "libstream_probe.so")
-    if not os.path.exists(path):
-        import subprocess
-        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared",
-                        os.path.join(ROOT, "tools", "stream_probe.hip"), "-o", path], check=True)
+    if not os.path.exists(path):      # built by __graft_entry__.build() only: this process has initialised the GPU and
+        raise RuntimeError("{} is absent (run __graft_entry__.build())".format(os.path.relpath(path, ROOT)))   # must not spawn a compiler
     lib = ctypes.CDLL(path)
     fn = lib.vqa_probe_stream
     fn.restype = ctypes.c_double
@@ -427,6 +567,64 @@ def attention_microbench(batch, heads, seq, with_bias, reps=10):
                        "per-kernel durations inside the attack: profiles/r03/bench_default_summary.txt".format(reps))
 
 
+def reference_style_leg(flavor, white, cfg, text_len, pgd_steps, reps=2):
+    """What a user of the reference gets from switching only the ``cleverhans`` import: the
+    reference's own call -- batch 1, its ``pgd_attack`` member as ``model_fn`` (torch.stack / cat-packed plain tensors,
+    ``[0]`` indexing: whitebox/reference_style.py after vlmo_module.py:1387-1446 / adv_attack.py:119-126),
+    ``pgd.projected_gradient_descent(model_fn, x, 0.125, 0.01, 40, np.inf, -1, 1, y=..., time=0, ori_x=..., ls=1)``
+    (adv_attack.py:607-610) -- through the drop-in operator, in ms per PGD iteration, next to the bundled batched
+    adapters (``LayerFeatures``, nothing packed) at the same batch 1."""
+    import numpy as np
+    from vqattack_amd import dropin
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox import reference_style
+    dev = next(white.parameters()).device
+    ids, masks, _ = synthetic_questions(1, text_len, seed=7, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    image = torch.empty(1, 3, cfg.image_size, cfg.image_size, device=dev).uniform_(-1, 1, generator=gen)
+    pgd = dropin.load(flavor).projected_gradient_descent.projected_gradient_descent
+    batch = dict(text_ids=ids, text_masks=masks)
+    if flavor == "vlmo":
+        me = reference_style.VlmoReferenceClosures(white, batch)
+        y = me.Gen_ori_feats(image)
+    else:
+        me = reference_style.AlbefReferenceClosures(white, batch)
+        img_feats, txt_feats = me.Gen_ori_feats(image)
+        y = [txt_feats, img_feats, None, None, None]
+
+    def reference_call():
+        with torch.enable_grad():
+            return pgd(me.pgd_attack, image, 0.125, 0.01, pgd_steps, np.inf, -1, 1, y=list(y), time=0, ori_x=image, ls=1)
+
+    if flavor == "vlmo":
+        from vqattack_amd.whitebox.vlmo import VlmoAttackAdapters as Adapters
+    else:
+        from vqattack_amd.whitebox.albef import AlbefAttackAdapters as Adapters
+    bundled = BatchedVQAttack(Adapters(white), flavor, white.embedding_tables(),
+                              AttackConfig(budget=pgd_steps, random_start=True, sanity_checks=True))
+    words = torch.zeros_like(ids, dtype=torch.bool)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps / pgd_steps * 1e3
+    ms_ref = timed(reference_call)
+    ms_bundled = timed(lambda: bundled.attack_batch(image, ids, masks, words))
+    return dict(what="the reference's own call at its own batch size 1: its pgd_attack member (packed plain tensors, [0] "
+                     "indexing) as model_fn through the drop-in projected_gradient_descent, {} steps, time=0, "
+                     "sanity_checks on".format(pgd_steps),
+                ms_per_pgd_iteration=round(ms_ref, 3), examples_per_sec=round(1e3 / (ms_ref * pgd_steps), 3),
+                bundled_adapters_ms_per_pgd_iteration=round(ms_bundled, 3),
+                bundled_adapters_examples_per_sec=round(1e3 / (ms_bundled * pgd_steps), 3),
+                loss_launches_per_iteration=2, note="wall clock incl. the one host read per PGD call; the two (output, "
+                "target) pairs of the packed form have different shapes (per-layer [CLS] rows / all token rows; text / "
+                "image maps), so they are two loss launches, not one pointer-table launch")
+
+
 def baseline_config(args):
     """Which entry of BASELINE.json's ``configs`` the run is (the default run is configs[1])."""
     full = args.pgd_steps == 40 and args.image_size == 384
@@ -501,7 +699,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.dry_run:
-        return dry_run(args, world, rank)
+        return dry_run_sweep(args, world, rank) if args.sweep else dry_run(args, world, rank)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # any torchrun launch, also N = 1
     if not torch.cuda.is_available():
@@ -532,6 +730,58 @@ def main():
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=True,   # the reference's
                                           live_mlm_rows=not args.dense_mlm))   # call sites use the default True (adv_attack.py:633-636)
+    identity = device_identity(dev_index)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.sweep:
+        # ---- BASELINE configs[3] as written: a fixed set, sharded; strong scaling
+        from vqattack_amd.attack.sweep import run_sweep
+        sweep_attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
+                                       AttackConfig(budget=args.pgd_steps, random_start=True))
+
+        last = [time.perf_counter()]
+
+        def progress(done, n_local):
+            if rank == 0 and time.perf_counter() - last[0] >= 45.0:
+                last[0] = time.perf_counter()
+                log("sweep: rank 0 has attacked {} of its {} samples".format(done, n_local))
+
+        def one_sweep(n, seed):
+            return run_sweep(flavor, white, black, adapters, n, args.batch, cfg.image_size, text_len, device, rank,
+                             world, joint=True, seed=seed, log_every=0,
+                             dual_every=args.dual_every, mixed=True, attack=sweep_attack, force_collective=use_dist,
+                             collective_device=coll_device, progress=progress)
+        if args.warmup:
+            one_sweep(args.warmup * args.batch * world, seed=977)
+            log("warm-up sweep of {} samples done".format(args.warmup * args.batch * world))
+        fence()
+        t0 = time.perf_counter()
+        results = [one_sweep(args.sweep, seed=1) for _ in range(args.steps)]
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        keys = ("seconds", "n_local", "n_batches", "gradient_steps", "global_steps", "gather_seconds", "n_dual_local")
+        record = [results[-1][k] if k in ("n_local", "n_dual_local") else sum(r[k] for r in results) for k in keys]
+        records, idents = gather_rank_records(record, identity, use_dist, coll_device)
+        check_distinct(idents, world, backend if use_dist else None)
+        if rank == 0:
+            line = sweep_line(args, world, results, dt, records, idents, dist.get_backend() if use_dist else None,
+                              flavor, text_len, cfg.image_size, gemms_tuned=bool(gemms_tuned))
+            line["seconds"] = round(dt, 3)
+            print(json.dumps(line), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     ledger = SuccessLedger(world, rank, coll_device, force_collective=use_dist)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -559,12 +809,6 @@ def main():
         ledger.record(adv_answers != clean_answers)     # sample ids default to this rank's interleaved shard
         return res
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         one_step()
         torch.cuda.synchronize()
@@ -585,6 +829,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     roof, roof_loss = timer.summary()
+    _, idents = gather_rank_records([0.0], identity, use_dist, coll_device)
+    check_distinct(idents, world, backend if use_dist else None)
     if rank == 0:
         log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 
@@ -612,6 +858,7 @@ def main():
                        "mean_real_tokens": round(sum(n_words) / len(n_words) + 2, 2), "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
+            "distinct_devices": len(set(idents)),       # GPUs (by UUID / PCI address) the ranks of this line computed on
             "tuned_gemms": ({"file": os.path.relpath(os.environ.get("VQA_TUNED_GEMMS", tuned_gemms.DEFAULT_FILE), ROOT),
                              **tuned_gemms.status()} if gemms_tuned else None),
             "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),
@@ -620,20 +867,33 @@ def main():
             "roofline": roof,
             "roofline_loss": roof_loss,
         }
+        # auxiliary legs: whatever goes wrong in one of them (absent or stale probe library, out of memory on a shared
+        # box, ...) is reported inside the line -- never allowed to suppress the metric line or to strand the other ranks
         if not args.no_b256:
             try:
                 line["platform_stream_probe"] = stream_probe()
+            except Exception as exc:
+                line["platform_stream_probe"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
+            try:
                 line["roofline_b256"] = step_kernel_microbench(256, cfg.image_size)
-            except RuntimeError as exc:            # e.g. out of memory on a shared box: report, do not hide
-                line["roofline_b256"] = {"error": str(exc)[:200]}
+            except Exception as exc:
+                line["roofline_b256"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
         if cfg.dim // cfg.heads == 64:                # the white box's attention runs on csrc/attn.hip
             seq = (n_body + 2 if flavor == "vlmo" else 0) + cfg.n_image_tokens
             try:
                 line["roofline_attention"] = attention_microbench(args.batch, cfg.heads, seq, flavor == "vlmo")
-            except RuntimeError as exc:
-                line["roofline_attention"] = {"error": str(exc)[:200]}
+            except Exception as exc:
+                line["roofline_attention"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
+        if not args.no_reference_style and args.model.endswith("_base"):
+            try:
+                line["reference_style"] = reference_style_leg(flavor, white, cfg, text_len, args.pgd_steps)
+            except Exception as exc:
+                line["reference_style"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
         if world == 1 and not args.no_cpu_baseline and flavor == "vlmo":
-            line["cpu_baseline"] = cpu_baseline(args, cfg)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, cfg)
+            except Exception as exc:
+                line["cpu_baseline"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -60,3 +60,12 @@ class ProductImpl:
 
     def pgd_vl(self, flavor):
         return self._load(flavor).projected_gradient_descent_vl.projected_gradient_descent
+
+
+def reference_closures(flavor, model, batch):
+    """The reference's own batch-1 ``model_fn`` members (``pgd_attack`` ... reading ``self.batch``, torch.stack / cat
+    packed plain tensors, ``[0]`` indexing) over a bundled white box -- NOT the oracle's adapters: this is the form a
+    user of the reference drives the drop-in with (``vqattack_amd/whitebox/reference_style.py``)."""
+    from vqattack_amd.whitebox import reference_style
+    cls = reference_style.VlmoReferenceClosures if flavor == "vlmo" else reference_style.AlbefReferenceClosures
+    return cls(model, batch)

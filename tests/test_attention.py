@@ -140,3 +140,69 @@ def test_key_hole_equals_the_dense_padding_mask(b, h, s):
             assert float(a.grad[i, lo:hi, 1:].abs().max()) == 0.0        # dK, dV rows of the hole
     with torch.no_grad():                                      # forward-only path (targets, black-box scoring)
         assert torch.equal(attention.self_attention_packed(qkv, khb), out_hole.detach())
+
+
+# ---- the reference's own resolution: 480 x 480 images = 30 x 30 + 1 = 901 image tokens (ALBEF_attack/configs/VQA.yaml:10,
+# vlmo/config.py:283-299).  VLMo: 40 text + 901 = 941 tokens, 915 after the padding trim of a 12-word batch; ALBEF's
+# fusion layers: <= 25 text queries over the 901 image keys (multiway_transformer.py:88-118, xbert.py cross attention).
+# More key tiles than any 384-px case (30 instead of 19-20), a ragged last tile (941 = 29 * 32 + 13), the lazy-max
+# rescale over a longer row, and saved scores / dS^T workspaces at (8 * 128) x (30 * 32) per (batch, head).
+@pytest.mark.parametrize("s", [915, 941])
+@pytest.mark.parametrize("form", ["saved_scores", "ds_workspace", "recompute"])
+def test_self_attention_at_the_480px_token_counts(s, form, monkeypatch):
+    from vqattack_amd import attention
+    if form != "saved_scores":
+        monkeypatch.setattr(attention, "SCORES_LIMIT", 0)
+    if form == "recompute":
+        monkeypatch.setattr(attention, "DS_WORKSPACE_LIMIT", 0)
+    b, h = 3, 12
+    g = torch.Generator(device=DEV).manual_seed(s)
+    qkv = torch.randn(b, s, 3, h, 64, device=DEV, generator=g)
+    slab = torch.zeros(1, h, s, (s + 31) // 32 * 32, device=DEV)
+    slab[..., :s] = torch.randn(1, h, s, s, device=DEV, generator=g) * 0.5
+    slab = slab[..., :s]
+    n_text = s - 901                                        # padded text keys of sample i: [n_i, n_text)
+    holes = [[6, n_text], [n_text, n_text], [n_text - 1, n_text]]
+    khb = attention.KeyHoleBias(slab.expand(b, -1, -1, -1), torch.tensor(holes, dtype=torch.int32, device=DEV))
+    dense = khb.dense()
+    go = torch.randn(b, s, h, 64, device=DEV, generator=g)
+    grads, outs = [], []
+    for _ in range(2):
+        a = qkv.clone().requires_grad_(True)
+        out = attention.self_attention_packed(a, khb)
+        out.backward(go)
+        grads.append(a.grad)
+        outs.append(out.detach())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(grads[0], grads[1])          # bitwise reproducible
+    ref_in = qkv.clone().requires_grad_(True)
+    ref = _sdpa(ref_in[:, :, 0], ref_in[:, :, 1], ref_in[:, :, 2], dense)
+    ref.backward(go)
+    assert torch.allclose(outs[0], ref, atol=2e-5, rtol=1e-5), float((outs[0] - ref).abs().max())
+    err = float((grads[0] - ref_in.grad).abs().max())
+    assert err <= 1e-4 * float(ref_in.grad.abs().max()), (err, float(ref_in.grad.abs().max()))
+    assert float(grads[0][0, 6:n_text, 1:].abs().max()) == 0.0                      # masked keys: no dK / dV
+
+
+@pytest.mark.parametrize("bias_kind", ["none", "shared"])
+@pytest.mark.parametrize("form", ["saved_scores", "ds_workspace", "recompute"])
+def test_cross_attention_25_text_queries_over_901_image_keys(bias_kind, form, monkeypatch):
+    from vqattack_amd import attention
+    if form != "saved_scores":
+        monkeypatch.setattr(attention, "SCORES_LIMIT", 0)
+    if form == "recompute":
+        monkeypatch.setattr(attention, "DS_WORKSPACE_LIMIT", 0)
+    b, h, sq, sk = 2, 12, 25, 901
+    q, k, v = (t.clone().requires_grad_(True) for t in _inputs(b, h, sq, sk, 11))
+    bias = (torch.randn(1, h, sq, sk, device=DEV) * 0.5).expand(b, -1, -1, -1) if bias_kind == "shared" else None
+    go = torch.randn(b, sq, h, 64, device=DEV)
+    out = attention.attention(q, k, v, bias)
+    out.backward(go)
+    got = [t.grad.clone() for t in (q, k, v)]
+    for t in (q, k, v):
+        t.grad = None
+    ref = _sdpa(q, k, v, bias)
+    ref.backward(go)
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5), float((out - ref).abs().max())
+    for name, g_, t in zip("qkv", got, (q, k, v)):
+        scale = float(t.grad.abs().max()) + 1e-6
+        assert float((g_ - t.grad).abs().max()) <= 1e-4 * scale, (name, float((g_ - t.grad).abs().max()), scale)

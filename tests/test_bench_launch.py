@@ -38,6 +38,40 @@ def test_gpus_2_without_launcher_env_runs_two_ranks():
     assert abs(rec["attack_success_rate"] - 4 / 10) < 1e-6       # ids 0..9 over both ranks, success iff id % 3 == 0
 
 
+def test_sweep_mode_is_a_fixed_set_sharded_over_eight_ranks():
+    """``bench.py --sweep N`` = BASELINE configs[3] as written: a FIXED seeded set sharded rank::world (strong scaling).
+    --dry-run, 8 ranks from a plain invocation: one line from rank 0 with per-rank samples / batches / steps / gather
+    time for every rank, the shards partition the set, the success rate is the one of the whole set."""
+    p = _run(["--gpus", "8", "--dry-run", "--sweep", "5003", "--batch", "64"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = lines[0]
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 8 and rec["dry_run"] is True and rec["value"] is None
+    assert rec["config"]["n_samples"] == 5003 and rec["collective"] == {"backend": "gloo", "world": 8, "calls": 2}
+    per = rec["per_rank"]
+    assert per["samples"] == [626, 626, 626, 625, 625, 625, 625, 625] and sum(per["samples"]) == 5003
+    assert all(len(per[k]) == 8 for k in per) and per["n_batches"] == [10] * 8
+    assert sum(per["dual_loss_samples"]) in (1251, 1252, 1253)           # one in four (+ a chance hit of the decision logic)
+    assert min(per["dual_loss_samples"]) >= 100                             # ... and on every rank, not on two of them
+    # every sample's own schedule: 40 image steps + one probe per substitutable word but the last block's
+    from vqattack_amd.attack.schedule import gradient_steps
+    from vqattack_amd.attack.sweep import synthetic_questions
+    ids, _, att = synthetic_questions(5003, 40, seed=0)
+    assert sum(per["sample_steps"]) == sum(gradient_steps(int(n), 40) for n in att.sum(dim=1).tolist())
+    assert rec["imbalance"]["sample_steps_max"] == max(per["sample_steps"])
+    assert abs(rec["attack_success_rate"] - float((ids[:, 1] % 3 == 0).float().mean())) < 1e-6
+    assert rec["distinct_devices"] == 1            # the dry run's ranks share the host; under RCCL it must equal n_gpus
+
+
+def test_sweep_mode_single_process():
+    p = _run(["--gpus", "1", "--dry-run", "--sweep", "37", "--batch", "8"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _json_lines(p.stdout)[0]
+    assert rec["n_gpus"] == 1 and rec["collective"] is None and rec["per_rank"]["samples"] == [37]
+    assert rec["per_rank"]["n_batches"] == [5]
+
+
 def test_world_size_mismatch_exits_non_zero():
     p = _run(["--gpus", "2", "--dry-run"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
              MASTER_PORT="29999")

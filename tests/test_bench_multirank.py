@@ -71,6 +71,38 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec["roofline"] is not None and rec["roofline"]["launches"] == 6 * steps and rec["vs_baseline"] is None
 
 
+def test_sweep_two_ranks_on_one_gpu(tmp_path):
+    """``bench.py --sweep 256`` (BASELINE configs[3]'s form: a fixed set, strong scaling) with two ranks rehearsing on the
+    one GPU: one line, 128 samples per rank, per-rank records of both ranks, ``distinct_devices == 1`` (under RCCL the
+    bench refuses a line whose ranks shared a GPU; the gloo rehearsal switch is what allows it here)."""
+    ctx = multiprocessing.get_context("forkserver")
+    world = 2
+    argv = ["--gpus", "2", "--sweep", "256", "--warmup", "1", "--model", "vlmo_tiny", "--batch", "32", "--pgd-steps", "8"]
+    port = _free_port()
+    outs = [str(tmp_path / "rank{}.out".format(r)) for r in range(world)]
+    procs = [ctx.Process(target=_bench_rank, args=(r, world, port, outs[r], argv)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=420)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join()
+            pytest.fail("a bench rank did not finish within 420 s")
+        assert p.exitcode == 0
+    lines = [ln for ln in open(outs[0]).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in open(outs[1]).read().splitlines() if ln.startswith("{")]
+    rec = json.loads(lines[0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["config"]["n_samples"] == 256
+    assert rec["per_rank"]["samples"] == [128, 128] and rec["per_rank"]["n_batches"] == [4, 4]
+    assert rec["distinct_devices"] == 1 and rec["collective"]["backend"] == "gloo" and rec["collective"]["calls"] == 2
+    assert abs(rec["value"] - 256 / rec["seconds"]) <= 0.01 * rec["value"]
+    assert rec["seconds"] >= max(rec["per_rank"]["seconds_attack"])          # max over ranks, gathers included
+    asr = rec["attack_success_rate"]
+    assert abs(asr * 256 - round(asr * 256)) < 1e-3, "the success rate is over the 256 gathered bits"
+
+
 def _plain_invocation(out_path, argv):
     """``python bench.py --gpus 2 ...`` WITHOUT a launcher environment, from a process that has not touched the GPU (the
     fork server's child): bench.py must start the two ranks itself (torch.distributed.run as a child process)."""

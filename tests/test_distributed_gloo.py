@@ -147,6 +147,18 @@ def test_two_rank_sweep_shard_ledger_gather(tmp_path, n_samples, mixed):
     assert got[0]["steps"] + got[1]["steps"] == int((40 + att.sum(dim=1)).sum())
 
 
+def test_sweep_with_fewer_samples_than_ranks(tmp_path):
+    """A rank whose shard is EMPTY (n_samples < world) still takes part in both all-gathers with its (0, L) rows -- it must
+    not raise before the collective and leave the other ranks waiting."""
+    world, n_samples = 2, 1
+    mp.spawn(_sweep_worker, args=(world, _free_port(), n_samples, True, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "s{}.pt".format(r))) for r in range(world)]
+    assert [g["n_local"] for g in got] == [1, 0] and got[1]["calls"] == []
+    for g in got:
+        _check_gathered_text(g["adv_text"], n_samples)
+        assert g["collectives"] == 2 and g["asr"] in (0.0, 1.0)
+
+
 def test_eight_rank_sweep_of_5003_samples_gathers_bits_and_text(tmp_path):
     """BASELINE configs[3]'s sharding at its real size (5k samples over 8 ranks, uneven shards: 5003 = 8 * 625 + 3) on
     gloo with the stand-in attack: ASR over all samples and the complete adversarial-text output on rank 0."""

@@ -186,6 +186,40 @@ def test_albef_vit_fused_encoder_equals_eager_blocks():
     _check_encoder(run, cfg.vit_depth + 1, 2e-5, 2e-4)
 
 
+@pytest.mark.parametrize("how", ["load_state_dict", "assign", "in_place"])
+def test_fused_encoder_follows_weight_updates(how):
+    """The cached fused spec holds packed COPIES of ALBEF's q / k / v weights (and aliases VLMo's): after a
+    load_state_dict (copying or assign=True) or an in-place update of the weights the fused path must run on the NEW
+    weights, like the eager blocks do."""
+    from vqattack_amd.whitebox.albef import AlbefConfig, FrozenAlbef
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo
+    acfg = AlbefConfig(dim=128, vit_depth=2, bert_depth=2, fusion_layer=1, heads=2, patch=8, image_size=32, n_answers=5,
+                       decoder_depth=1, k_test=3, mlm_probability=0.0)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    image = torch.empty(2, 3, 32, 32, device=DEV).uniform_(-1, 1, generator=g)
+    ids = torch.tensor([[101, 5, 6, 7, 102, 0, 0, 0], [101, 8, 9, 102, 0, 0, 0, 0]], device=DEV)
+    for make, fwd in ((lambda seed: FrozenAlbef(acfg, seed=seed).to(DEV), lambda m: m.visual_encoder(image)[0]),
+                      (lambda seed: FrozenVlmo(_vlmo_small(), seed=seed).to(DEV),
+                       lambda m: m.encode(image, m.text_embeddings(ids), (ids != 0).long())[1])):
+        model, donor = make(4), make(9)
+        with torch.no_grad():
+            model.fused_blocks = True
+            before = fwd(model).clone()
+            if how == "load_state_dict":
+                model.load_state_dict(donor.state_dict())
+            elif how == "assign":
+                model.load_state_dict(donor.state_dict(), assign=True)
+            else:
+                for p, q in zip(model.parameters(), donor.parameters()):
+                    p.copy_(q)
+            fused = fwd(model)
+            model.fused_blocks = False
+            eager = fwd(model)
+        assert float((fused - before).abs().max()) > 1e-2, "the donor's weights should change the output"
+        assert float((fused - eager).abs().max()) <= 2e-5 * float(eager.abs().max()), \
+            "the fused encoder still runs on the weights of before the update ({})".format(how)
+
+
 def test_vlmo_base_fused_encoder_equals_eager_blocks_and_frees_its_activations():
     """BASELINE configs[1] shape (12 x 768, 587-token layout), batch 2; afterwards no activation of the call is alive
     (outputs saved through save_for_backward: no reference cycle through the graph)."""

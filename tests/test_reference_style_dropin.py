@@ -1,0 +1,111 @@
+"""The drop-in driven the way a user of the reference drives it, at BASELINE model size.
+
+The reference's orchestrators call ``pgd.projected_gradient_descent(self.pgd_attack, adv_img, 0.125, 0.01, iter, np.inf,
+-1, 1, y=[...], time=ii, ori_x=..., ls=...)`` (``adv_attack.py:633-636``, ``vlmo_module.py:1973-1976``) with closures that
+are members of the attack class: ONE sample, ``torch.stack`` / ``torch.cat``-packed plain tensors, ``[0]`` indexing
+(``vlmo_module.py:1387-1446``, ``adv_attack.py:119-126``).  Here exactly that form (tests/adapters.reference_closures over
+the bundled white box on the GPU) goes through the drop-in MODULE PATH
+``vqattack_amd/dropin/<flavor>/cleverhans/torch/attacks/projected_gradient_descent.py`` and is compared with the CPU
+oracle (``oracle.cleverhans_cpu`` + ``oracle/adapters_ref.py``) on the same inputs.  Tolerances: those of
+tests/test_fullsize_parity.py for <= 8 steps (>= 99.9 % of the pixels bit-identical, |dev| <= 2 eps_iter steps, losses
+1e-4 relative).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.adapters import reference_closures
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+EPS, EPS_ITER = 0.125, 0.01
+
+
+def _dropin_pgd(flavor):
+    """``projected_gradient_descent`` of the FILE a switched driver imports:
+    ``<repo>/vqattack_amd/dropin/<flavor>/cleverhans/torch/attacks/projected_gradient_descent.py`` (executed from its path;
+    both flavors' packages are named ``cleverhans``, so they cannot both sit on sys.path of one test process)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "vqattack_amd", "dropin", flavor, "cleverhans", "torch", "attacks",
+                        "projected_gradient_descent.py")
+    spec = importlib.util.spec_from_file_location("dropin_{}_pgd".format(flavor), path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.projected_gradient_descent
+
+
+def _question(n_words, text_len, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(1, text_len, dtype=torch.long)
+    ids[0, 0] = 101
+    ids[0, 1:1 + n_words] = torch.randint(1000, 30522, (n_words,), generator=g)
+    ids[0, 1 + n_words] = 102
+    return ids, (ids != 0).long(), g
+
+
+def _same(got, want, steps):
+    same = float((got == want).float().mean())
+    assert same >= 0.999, "only {:.3%} of the pixels are bit-identical".format(same)
+    assert float((got - want).abs().max()) <= 2 * EPS_ITER * steps + 1e-6
+    return same
+
+
+@pytest.mark.parametrize("image_size", [384])
+def test_vlmo_base_reference_style_closure_through_the_dropin_module(image_size):
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import VlmoRefAdapters
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, vlmo_base
+    steps = 8
+    cpu_model = FrozenVlmo(vlmo_base(image_size), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, g = _question(7, 40, seed=3)
+    img = torch.empty(1, 3, image_size, image_size).uniform_(-1, 1, generator=g)
+    start = torch.clamp(img + torch.empty_like(img).uniform_(-EPS, EPS, generator=g), -1, 1)   # time != 0: no random init
+    # ---- the reference's call, on the device, through the module path
+    pgd = _dropin_pgd("vlmo")
+    me = reference_closures("vlmo", gpu_model, dict(text_ids=ids.to(DEV), text_masks=masks.to(DEV)))
+    y = me.Gen_ori_feats(img.to(DEV))
+    assert [tuple(t.shape) for t in y] == [(1, 768), (13, 768), (13, 9 + 577, 768)]           # packed plain tensors
+    with torch.enable_grad():
+        adv, losses = pgd(me.pgd_attack, start.to(DEV), EPS, EPS_ITER, steps, np.inf, -1, 1, y=y, time=1,
+                          ori_x=img.to(DEV), ls=1)
+    # ---- the CPU oracle with the oracle's own restatement of the packing
+    ad = VlmoRefAdapters(cpu_model, ids, masks)
+    with torch.enable_grad():
+        want, want_losses = oracle.projected_gradient_descent(ad.pgd_attack, start, EPS, EPS_ITER, steps, np.inf,
+                                                              clip_min=-1, clip_max=1, y=ad.gen_ori_feats(img), ori_x=img,
+                                                              time=1, ls=1, flavor="vlmo")
+    _same(adv.cpu(), want.detach(), steps)
+    assert len(losses) == steps
+    np.testing.assert_allclose(losses, want_losses, rtol=1e-4)
+
+
+def test_albef_base_reference_style_closure_through_the_dropin_module():
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import AlbefRefAdapters
+    from vqattack_amd.whitebox.albef import FrozenAlbef, albef_base
+    steps = 4
+    cpu_model = FrozenAlbef(albef_base(384, mlm_probability=0.0), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, g = _question(6, 8, seed=5)
+    img = torch.empty(1, 3, 384, 384).uniform_(-1, 1, generator=g)
+    start = torch.clamp(img + torch.empty_like(img).uniform_(-EPS, EPS, generator=g), -1, 1)
+    pgd = _dropin_pgd("albef")
+    me = reference_closures("albef", gpu_model, dict(text_ids=ids.to(DEV), text_masks=masks.to(DEV)))
+    img_feats, txt_feats = me.Gen_ori_feats(img.to(DEV))
+    assert tuple(img_feats.shape) == (13, 577, 768) and tuple(txt_feats.shape) == (13, 8, 768)
+    with torch.enable_grad():                          # adv_attack.py:633-636: y = [txt, img, ...]
+        adv, losses = pgd(me.pgd_attack, start.to(DEV), EPS, EPS_ITER, steps, np.inf, -1, 1,
+                          y=[txt_feats, img_feats, None, None, None], time=1, ori_x=img.to(DEV), ls=1)
+    ad = AlbefRefAdapters(cpu_model, ids, masks)
+    tgt = ad.gen_ori_feats(img)
+    with torch.enable_grad():
+        want, want_losses = oracle.projected_gradient_descent(ad.pgd_attack, start, EPS, EPS_ITER, steps, np.inf,
+                                                              clip_min=-1, clip_max=1, y=[tgt[0], tgt[1], None, None, None],
+                                                              ori_x=img, time=1, ls=1, flavor="albef")
+    _same(adv.cpu(), want.detach(), steps)
+    np.testing.assert_allclose(losses, want_losses, rtol=1e-4)

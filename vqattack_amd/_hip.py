@@ -89,6 +89,11 @@ def load_library(path=None):
         raise HipExtensionError(
             "HIP kernel library not found at {} -- build it with `python -m vqattack_amd.build` "
             "(or __graft_entry__.build()); vqattack_amd has no CPU or eager fallback".format(path))
+    if tuning and path == TUNING_LIB_PATH:
+        from . import build as _build          # an A/B run on kernels older than the sources would measure nothing
+        if _build._stale(path):
+            raise HipExtensionError("{} is older than vqattack_amd/csrc: rebuild it with `python -m vqattack_amd.build "
+                                    "--tuning`".format(path))
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

@@ -82,7 +82,7 @@ class SuccessLedger:
         the sweep, adv_attack.py:734-735 / vlmo_module.py:2095-2097): ONE padded all-gather of ``(cap, 1 + L)`` words
         ``[sample id, row...]``.  Returns ``(ids (n_total,), rows (n_total, L))`` sorted by sample id, on every rank."""
         ids = torch.as_tensor(sample_ids, dtype=torch.int64, device=self.device).reshape(-1)
-        rows = rows.to(self.device, torch.int64).reshape(ids.numel(), -1)
+        rows = rows.to(self.device, torch.int64).reshape(ids.numel(), rows.shape[-1])   # (0, L) stays (0, L): an empty shard
         if self.world == 1 and not self.force_collective:
             order = torch.argsort(ids)
             return ids[order], rows[order]

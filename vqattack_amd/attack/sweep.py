@@ -21,20 +21,24 @@ def synthetic_mlm_tasks(ids, dual_every, flavor, seed=0, max_len=None):
     declarative paraphrase: ``vilt_ans_table``, ``all_correct_ans``, ``chatgpt`` tables, adv_attack.py:62-79), fed through
     the real decision logic ``mlm_task.build_mlm_task`` (adv_attack.py:433-558).
 
-    Paraphrase of sample s = its question words followed by one answer word.  Every ``dual_every``-th sample's victim
-    answer IS that word (-> old_alg = 0: the word is [MASK]-ed and becomes the MLM label; every third of those has a
-    second correct answer of the same piece count -> 3-d labels); the other samples' victim answer does not occur in
-    the paraphrase (-> old_alg = 1, feature loss only).  Returns one ``MlmTask`` per sample."""
+    Paraphrase of sample s = its question words followed by one answer word.  One sample in ``dual_every`` -- exactly
+    ceil(n / dual_every) of them, spread over the set by a seeded permutation, NOT every dual_every-th index: with the
+    sweep's interleaved ``rank::world`` shards a periodic pattern would put every dual-loss sample of a 5k sweep on two
+    of eight ranks -- has a victim answer that IS that word (-> old_alg = 0: the word is [MASK]-ed and becomes the MLM
+    label; every third of those has a second correct answer of the same piece count -> 3-d labels); the other samples'
+    victim answer does not occur in the paraphrase (-> old_alg = 1, feature loss only).  Returns one ``MlmTask`` per
+    sample."""
     from . import mlm_task
     r = np.random.RandomState(seed + 1)
+    slot = np.random.RandomState(seed + 7).permutation(ids.shape[0])      # sample -> its slot in the dual pattern
     tasks = []
     for s in range(ids.shape[0]):
         body = [(int(t),) for t in ids[s].tolist() if t not in (0, 101, 102)]
         in_para, other, alt = (int(v) for v in r.randint(1000, 30522, 3))
         para = body + [(in_para,)]
-        is_dual = bool(dual_every) and s % dual_every == 0
+        is_dual = bool(dual_every) and int(slot[s]) % dual_every == 0
         answer = [(in_para,)] if is_dual else [(other,)]
-        correct = [answer, [(alt,)]] if (is_dual and (s // dual_every) % 3 == 0) else [answer]
+        correct = [answer, [(alt,)]] if (is_dual and (int(slot[s]) // dual_every) % 3 == 0) else [answer]
         tasks.append(mlm_task.build_mlm_task(answer, correct, [True] + [False] * (len(correct) - 1), para, [], flavor,
                                              max_len=max_len))
     return tasks
@@ -66,9 +70,14 @@ def synthetic_images(qids, image_size, device):
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
               config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False,
-              attack=None, force_collective=False):
-    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps, n_batches, mean_batch)`` on
-    every rank.
+              attack=None, force_collective=False, collective_device=None, progress=None):
+    """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps, n_batches, mean_batch,
+    global_steps, batch_global_steps, gather_seconds, adv_text, collectives)`` on every rank: ``seconds`` is this rank's
+    attack + scoring time (device drained), ``gather_seconds`` the time of the two small all-gathers that follow (success
+    bits, adversarial text) including the wait for the slowest rank -- on a sharded sweep that wait IS the shard
+    imbalance; ``global_steps`` the white-box forward + backward passes this rank ran (a mixed batch runs as many as its
+    longest sample needs), ``gradient_steps`` the sum over its samples of each sample's own gradient steps.
+    ``progress(done, n_local)``: called after every batch (bench.py: a line per minute for the GPU box's liveness check).
     ``attack``: a ready ``BatchedVQAttack`` (or an object with its ``attack_batch`` / ``attack_mixed`` / ``cfg``) instead
     of one built from ``adapters`` -- the multi-rank CPU tests inject a stand-in to exercise shard -> ledger -> gather.
 
@@ -83,7 +92,10 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     device = torch.device(device)
     if attack is None:
         attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
-    ledger = SuccessLedger(world, rank, device, force_collective=force_collective)   # True: a 1-rank torchrun launch
+    # collective_device: where the gathered tensors live -- the compute device under RCCL (default); the host when several
+    # ranks rehearse on ONE GPU over gloo (bench.py, VQA_DIST_BACKEND=gloo)
+    ledger = SuccessLedger(world, rank, collective_device if collective_device is not None else device,
+                           force_collective=force_collective)   # True: a 1-rank torchrun launch
     # one bucket per (schedule, loss mode): a batch shares its block structure and its old_alg;
     # with mixed=True all samples share ONE bucket (key -2) and are scheduled per sample inside the batch
     buckets = bucket_by_schedule([(-2 if mixed else int(att[i].sum()) * 2 + int(dual[i])) for i in mine])
@@ -95,6 +107,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     steps = 0
     done = 0
     n_batches = 0
+    batch_global_steps = []
     t0 = time.perf_counter()
     for key, local in buckets.items():
         n_words, is_dual = key // 2, bool(key % 2)
@@ -120,6 +133,7 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
             ledger.record(after != clean, sample_ids=qids)
             # per-sample gradient steps, the same quantity on the bucketed and on the mixed path
             steps += res.sample_steps or res.gradient_steps * (1 if key == -2 else len(qids))
+            batch_global_steps.append(int(res.global_steps or (res.gradient_steps if key != -2 else 0)))
             if key != -2:
                 assert res.gradient_steps == gradient_steps(n_words, attack.cfg.budget)
             adv_rows.append(res.adv_text_ids[:, :text_len])        # stays on the device until the sweep's one gather
@@ -128,6 +142,8 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
                 writer.write(res.adv_images, qids)
             done += len(qids)
             n_batches += 1
+            if progress is not None:
+                progress(done, len(mine))
             if rank == 0 and log_every and done % log_every < len(qids):
                 bits = ledger.local_bits()
                 print("attack_accuracy", float(bits.float().mean().item()), "({} local samples)".format(done),
@@ -137,13 +153,18 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
     asr = ledger.all_gather_rate(n_samples)
     # the sweep's second output: every sample's adversarial question on every rank (rank 0 writes the json the reference
     # writes at the end, adv_attack.py:734-735 / vlmo_module.py:2095-2097) -- one small all-gather of (qid, ids) rows
     rows = torch.cat(adv_rows) if adv_rows else torch.zeros(0, text_len, dtype=torch.int64, device=device)
     all_q, all_rows = ledger.all_gather_rows(adv_qids, rows, n_samples)
-    adv_text = {str(q): row for q, row in zip(all_q.cpu().tolist(), all_rows.cpu().tolist())}
+    all_q, all_rows = all_q.cpu(), all_rows.cpu()          # drains the gathers
+    gather_dt = time.perf_counter() - t1
+    adv_text = {str(q): row for q, row in zip(all_q.tolist(), all_rows.tolist())}
     return dict(asr=asr, n_total=n_samples, n_local=len(mine), seconds=dt,
                 examples_per_sec_local=len(mine) / dt if dt > 0 else None, gradient_steps=steps, adv_text=adv_text,
                 n_batches=n_batches, mean_batch=(len(mine) / n_batches if n_batches else 0.0),
+                global_steps=sum(batch_global_steps), batch_global_steps=batch_global_steps, gather_seconds=gather_dt,
+                n_dual_local=int(sum(bool(dual[i]) for i in mine)),
                 collectives=ledger.collectives)

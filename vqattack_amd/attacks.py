@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._hip import VQA_FLAG_DEGENERATE, HipExtensionError
+from ._hip import VQA_FLAG_BAD_LABEL, VQA_FLAG_DEGENERATE, VQA_FLAG_RANGE, HipExtensionError
 from .features import LayerFeatures, layer_pairs
 
 ALBEF = "albef"
@@ -320,14 +320,18 @@ def _fgm_then_project(x, grad, x0, eps_iter, eps, norm, clip_min, clip_max, out,
 
 def _check_flag(flag, norm, sanity_checks):
     """The one host read of an operator call's flag word.  The degenerate-gradient bit is the reference's unconditional
-    ``assert`` inside ``optimize_linear`` (norm 1 / 2 only); range and label bits are ``sanity_checks`` material.
-    Returns True when no sanity bit is set."""
+    ``assert`` inside ``optimize_linear`` (norm 1 / 2 only, utils.py:101-104,110-116); the range and label bits are
+    ``sanity_checks`` material and are not looked at without it (the reference evaluates its range asserts only under
+    ``sanity_checks``: fast_gradient_method.py:162-163).  Returns True when no sanity bit counts against the call."""
     if flag is None or not (sanity_checks or norm != np.inf):
         return True
     bits = int(flag.item())
     assert not bits & VQA_FLAG_DEGENERATE, \
         "optimize_linear: the optimal perturbation does not have unit norm (all-zero or non-finite gradient)"
-    return (bits & ~VQA_FLAG_DEGENERATE) == 0
+    if not sanity_checks:
+        return True
+    assert not bits & VQA_FLAG_BAD_LABEL, "an MLM label is outside [0, vocabulary) and is not ignore_index"
+    return (bits & VQA_FLAG_RANGE) == 0
 
 
 def _grad_of(leaf):

@@ -41,6 +41,14 @@ def supported(dim, heads):
     return dim % heads == 0 and dim // heads == _attn.HEAD_DIM and dim % 4 == 0 and dim <= 1024
 
 
+def weights_key(module):
+    """Fingerprint of the frozen weights a spec was built from: storage address and in-place version counter of every
+    parameter.  ``load_state_dict`` (copy or ``assign=True``), ``.to()`` and any in-place update change it, so a cached
+    spec -- which may hold COPIES (ALBEF's packed q/k/v, contiguous copies of strided parameters) -- is rebuilt instead
+    of silently running on stale weights.  ~0.1 us per parameter, once per encoder pass."""
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
 def _c(t):
     t = t.detach()
     return t if t.is_contiguous() else t.contiguous()

@@ -221,9 +221,10 @@ class FrozenAlbef(nn.Module):
             image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
         x = torch.cat([self.cls_token.expand(b, -1, -1), self.patch_proj(patches)], dim=1) + self.pos_embed
         if self.fused_blocks and x.is_cuda and x.dtype == torch.float32 and _fused.supported(self.cfg.dim, self.cfg.heads):
-            if self._fused_spec is None:
-                self._fused_spec = _fused.vit_spec(self.vit_blocks, self.vit_norm, self.cfg.heads)
-            feats, states = _fused.encode(x, self._fused_spec, None, 0)
+            key = (_fused.weights_key(self.vit_blocks), _fused.weights_key(self.vit_norm))
+            if self._fused_spec is None or self._fused_spec[0] != key:      # the spec holds packed COPIES of q / k / v
+                self._fused_spec = (key, _fused.vit_spec(self.vit_blocks, self.vit_norm, self.cfg.heads))
+            feats, states = _fused.encode(x, self._fused_spec[1], None, 0)
             return states, feats
         feats = [x]
         for blk in self.vit_blocks:

@@ -1,0 +1,77 @@
+"""The reference's OWN ``model_fn`` closures over the bundled frozen white boxes -- what a user of the reference has.
+
+The batched drivers of this package (``attack/runner.py``) hand the operators ``LayerFeatures`` (per-layer maps left
+where the encoder wrote them, batch > 1, row weights).  A user who switches only the ``cleverhans`` import
+ keeps the reference's orchestrator instead, whose closures are members of the attack class
+that read ``self.batch``, run ONE sample and hand back ``torch.stack`` / ``torch.cat``-packed plain tensors:
+
+  * VLMO  ``pgd_attack`` vlmo_module.py:1387-1446 -> ``[pooler(cls) (1, D), cls per layer (depth+1, D),
+          tokens per layer (depth+1, n_real_text + n_image, D)]`` (``[0]`` indexing: batch 1; padded text tokens dropped
+          with ``torch.where``; the image part starts at the literal text length 40), ``pgd_attack_vl`` :1328-1385
+          (``x = [image, text_embeds]``), ``pgd_mlm_attack`` :1448-1529 (``[mlm logits, cls per layer, tokens]``),
+          ``Gen_ori_feats`` :1287-1312;
+  * ALBEF ``pgd_attack`` adv_attack.py:119-126 -> ``[cat(text maps, 0) (13 B, L, D), cat(image maps, 0) (13 B, N, D)]``,
+          ``pgd_attack_vl`` :208-214, ``pgd_mlm_attack`` :130-140 (``[mlm logits]``), ``Gen_ori_feats`` :111-118.
+
+These classes are that form, written against ``FrozenVlmo`` / ``FrozenAlbef``: a mutable ``batch`` dict the caller
+updates between operator calls (``adv_attack.py:631-632``), plain-tensor lists out.  They exist so that the drop-in is
+exercised and timed the way the reference would drive it (``tests/test_reference_style_dropin.py``,
+``bench.py --reference-style``); the packing copies they make are the reference's, not something the batched path does.
+"""
+import torch
+
+
+class VlmoReferenceClosures:
+    """``self.batch``: ``text_ids`` / ``text_masks`` (1, L) and, for the MLM closure, ``text_ids_mlm`` /
+    ``text_mask_mlm`` -- the keys the reference's closures read."""
+
+    def __init__(self, model, batch):
+        self.model, self.batch = model, batch
+
+    def _packed(self, feats, states, text_masks):
+        target = torch.stack(feats, axis=1)                                  # (1, depth + 1, L + N, D)
+        image_part = target[0, :, self.model.cfg.max_text_len:]              # the reference's literal 40
+        real_text = torch.where(text_masks[0] == 1)
+        per_token = torch.cat([target[0, :, real_text[0]], image_part], axis=1)
+        return self.model.pooled(states), target[0, :, 0, :], per_token
+
+    def pgd_attack(self, x):
+        ids, masks = self.batch["text_ids"], self.batch["text_masks"]
+        feats, states = self.model.encode(x, self.model.text_embeddings(ids), masks)
+        return list(self._packed(feats, states, masks))
+
+    def pgd_attack_vl(self, x):
+        masks = self.batch["text_masks"]
+        feats, states = self.model.encode(x[0], x[1], masks)
+        return list(self._packed(feats, states, masks))
+
+    def pgd_mlm_attack(self, x):
+        ids, masks = self.batch["text_ids_mlm"], self.batch["text_mask_mlm"]
+        feats, states = self.model.encode(x, self.model.text_embeddings(ids), masks)
+        _, per_layer_cls, per_token = self._packed(feats, states, masks)
+        return [self.model.mlm_score(states[:, :self.model.cfg.max_text_len]), per_layer_cls, per_token]
+
+    def Gen_ori_feats(self, image):
+        with torch.no_grad():
+            return [t.detach() for t in self.pgd_attack(image)]
+
+
+class AlbefReferenceClosures:
+    def __init__(self, model, batch):
+        self.model, self.batch = model, batch
+
+    def pgd_attack(self, x):
+        img, txt = self.model.gen_feats(x, self.batch["text_ids"], self.batch["text_masks"])
+        return [torch.cat(txt, axis=0), torch.cat(img, axis=0)]
+
+    def pgd_attack_vl(self, x):
+        img, txt = self.model.gen_feats_from_embeds(x[0], x[1], self.batch["text_ids"], self.batch["text_masks"])
+        return [torch.cat(txt, axis=0), torch.cat(img, axis=0)]
+
+    def pgd_mlm_attack(self, x):
+        return [self.model.get_mlm_logits(x, self.batch["text_ids_mlm"], self.batch["text_mask_mlm"])]
+
+    def Gen_ori_feats(self, image):
+        with torch.no_grad():
+            txt, img = self.pgd_attack(image)
+        return img.detach(), txt.detach()                                    # the reference's order: image first

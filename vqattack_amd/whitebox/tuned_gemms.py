@@ -1,14 +1,17 @@
-"""Pre-selected hipBLASLt solutions for the white boxes' fp32 GEMMs (PyTorch TunableOp, read-only).
+"""Pre-selected library solutions (hipBLASLt or rocBLAS) for the white boxes' fp32 GEMMs (PyTorch TunableOp, read-only).
 
 The attack's device time is ~72 % library fp32 GEMMs (the frozen encoders' projections and expert FFNs, forward and
-input-gradient backward: ``torch.addmm`` / ``torch.mm`` in ``whitebox/_fused.py``).  hipBLASLt's default heuristic picks
-one solution per shape; for a few of the attack's shapes another solution of the same library is faster.
+input-gradient backward: ``torch.addmm`` / ``torch.mm`` in ``whitebox/_fused.py``).  The library's default heuristic picks
+one solution per shape; for a few of the attack's shapes another solution (of hipBLASLt, or rocBLAS's own kernel: the
+recorded file holds both kinds, `Gemm_Hipblaslt_*` and `Gemm_Rocblas_*`) is faster.
 ``tools/tune_gemms.sh`` lets TunableOp time every solution for the shapes of a workload on an MI355X and records the
 winners; the result (a CSV of shape -> solution index, with the PyTorch / ROCm / hipBLASLt / gfx versions it is valid for)
 is tracked under ``vqattack_amd/tuning/``.  ``enable()`` loads it with tuning switched OFF: shapes in the file run the
 recorded solution, every other shape the library default; a file recorded for another software stack fails TunableOp's
 validators and is ignored (library defaults everywhere) -- so this is never a correctness dependency, and the
-arithmetic stays the library's fp32 GEMM.
+arithmetic stays the library's fp32 GEMM.  Every recorded entry is checked on the GPU for run-to-run bit stability and
+against the default solution (``tests/test_tuned_gemms.py``), and a white-box attack step with the file active is
+required to be bitwise reproducible.
 """
 import os
 

@@ -318,9 +318,10 @@ class FrozenVlmo(nn.Module):
         if bias is None:
             bias = self.attention_bias(text_masks)
         if self.fused_blocks and x.is_cuda and x.dtype == torch.float32 and _fused.supported(self.cfg.dim, self.cfg.heads):
-            if self._fused_spec is None:
-                self._fused_spec = _fused.vlmo_spec(self)
-            return _fused.encode(x, self._fused_spec, bias, n_text)
+            key = (_fused.weights_key(self.blocks), _fused.weights_key(self.norm))
+            if self._fused_spec is None or self._fused_spec[0] != key:      # load_state_dict / in-place weight updates
+                self._fused_spec = (key, _fused.vlmo_spec(self))
+            return _fused.encode(x, self._fused_spec[1], bias, n_text)
         feats = [x]
         for li, blk in enumerate(self.blocks):
             x = blk(x, bias[li], n_text)
