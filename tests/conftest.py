@@ -24,6 +24,30 @@ def pytest_configure(config):
         pass
 
 
+def usable_cores(cap=16):
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota.  A one-GPU job on the GPU box
+    gets a 16-core share of a much larger host, and torch sizes its intra-op pool by the HOST's core count: the CPU
+    oracle's many small ops then wake a hundred threads that share 16 cores."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_thread_pool():
+    """Size torch's CPU thread pool for the cores the job really has (the CPU oracle side of every parity test)."""
+    import torch
+    before = torch.get_num_threads()
+    torch.set_num_threads(usable_cores())
+    yield
+    torch.set_num_threads(before)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _kernel_library():
     """Build the HIP kernel library when it is missing or older than its sources (a fresh clone has no .so: built

@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--cache", default=os.path.join(ROOT, "gpurun_out", "asr_cache"))   # gpurun_out/ never travels to the GPU box
     ap.add_argument("--out", default=None)
+    ap.add_argument("--upto", type=int, default=None,
+                    help="attack and score only the first UPTO samples of the --n sample set (the inputs are still those of "
+                         "the n-sample draw: the random start of sample s depends on n); the fixture records n_scored. "
+                         "Turns an interrupted run's cache into a usable fixture")
     ap.add_argument("--sizes", default=None,
                     help="comma list of closed-answer-set sizes to score (default: CANDIDATE_SIZES); the attack results are "
                          "cached, so re-scoring with other sizes costs minutes")
@@ -83,14 +87,21 @@ def main():
     shape = SHAPE[flavor]
     samples = tsb.make_samples(flavor, cfg, n=args.n, seed=args.seed, **shape)
     ids, masks, att, _tasks, oracle_tasks, images, eta = samples
+    n_all = args.n
+    if args.upto is not None:            # a prefix of the set: everything below runs over the first `upto` samples
+        args.n = min(args.upto, n_all)
+        ids, masks, att, images, eta = ids[:args.n], masks[:args.n], att[:args.n], images[:args.n], eta[:args.n]
+        oracle_tasks = oracle_tasks[:args.n]
     sim = text_update.BagOfEmbeddingsSimilarity(seed=5)
-    prop_path = os.path.join(cache, "proposals_n{}.json".format(args.n))
+    prop_path = os.path.join(cache, "proposals_n{}.json".format(n_all))
     if os.path.exists(prop_path):
         proposals = [[(int(p), [int(v) for v in vs]) for p, vs in row] for row in json.load(open(prop_path))]
     else:
         log("candidate proposals on the CPU ...")
-        proposals = proposals_on_cpu(adapters_cls(white), ids, masks, att)
+        full = tsb.make_samples(flavor, cfg, n=n_all, seed=args.seed, **shape)
+        proposals = proposals_on_cpu(adapters_cls(white), full[0], full[1], full[2])
         json.dump(proposals, open(prop_path, "w"))
+    proposals = proposals[:args.n]
 
     # ---- the attack (never sees the victim): once per sample, cached
     t0 = time.perf_counter()
@@ -158,7 +169,7 @@ def main():
     bits = [int(a != c) for a, c in zip(after, clean)]
     rec = dict(
         note="generated by tests/golden/make_asr_fixture.py in the build container (CPU oracle); data only",
-        flavor=flavor, size="base", n=args.n, seed=args.seed, budget=args.budget, sim_threshold=0.3, sim_seed=5,
+        flavor=flavor, size="base", n=n_all, n_scored=args.n, seed=args.seed, budget=args.budget, sim_threshold=0.3, sim_seed=5,
         white_seed=3, black_seed=4, shape=dict(words=list(shape["words"]), max_att=shape["max_att"],
                                                text_len=shape["text_len"]),
         n_answers=pick, oracle_asr=asr[pick], oracle_asr_by_answer_set_size={str(k): v for k, v in asr.items()},

@@ -22,7 +22,6 @@ equal, substituted ids equal, success bits equal except where the victim is tied
 RATE per flavor and pooled within 0.5 %, and -- full mode, >= 2000 pooled samples -- the 95 % interval of the paired
 difference of the two rates inside +-0.5 % as well; every number is printed.
 """
-import copy
 import json
 import os
 
@@ -43,7 +42,19 @@ FIXTURES = [("asr_base_vlmo.json", "vlmo"), ("asr_base_albef.json", "albef")]
 TIE = 1e-3          # oracle decision margin (gap between the victim's two leading answers) below which a sample is a tie
 RESULTS = {}        # fixture -> dict(flavor, n, want bits, got bits, margins, sample ids), for the pooled test
 FULL = os.environ.get("VQA_ASR_FULL", "") not in ("", "0")
-SUBSET = dict(vlmo=64, albef=32)     # driver-run suite: the first K samples of every fixture file
+SUBSET = dict(vlmo=32, albef=16)     # driver-run suite: the first K samples of every fixture file
+_MODELS = {}        # (flavor, answer-set size of the ALBEF victim) -> (white on the GPU, black on the GPU, adapters, cfg)
+
+
+def _models(flavor, k, dev):
+    """The frozen pair of a flavor, built ONCE for all fixture files (same seeds in every file; the ALBEF victim's
+    answer list depends on its size): most of a small set's wall time is the CPU-side construction of the base models."""
+    key = (flavor, k if flavor == "albef" else None)
+    if key not in _MODELS:
+        cfg_kw = dict(n_answers=k, k_test=min(128, k)) if flavor == "albef" else {}
+        white, black, adapters_cls, _, cfg = tsb.build(flavor, "base", **cfg_kw)
+        _MODELS[key] = (white.to(dev), black.to(dev), adapters_cls, cfg)
+    return _MODELS[key]
 FIXTURES += sorted((os.path.basename(p), os.path.basename(p).split("_")[2])
                    for p in glob.glob(os.path.join(ROOT, "tests", "golden", "asr_base_*_*.json")))
 
@@ -63,18 +74,17 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
     rec = _fixture(name, flavor)
     assert rec["size"] == "base" and 0.3 <= rec["oracle_asr"] <= 0.7, "the fixture must be informative"
-    n_all, k = rec["n"], rec["n_answers"]
-    n = n_all if FULL else min(n_all, SUBSET[flavor])
+    n_all, k = rec["n"], rec["n_answers"]               # n_all: size of the seeded draw that regenerates the inputs
+    n_have = rec.get("n_scored", n_all)                 # ... of which the oracle attacked and scored a prefix
+    n = n_have if FULL else min(n_have, SUBSET[flavor])
     dev = torch.device("cuda", 0)
-    cfg_kw = dict(n_answers=k, k_test=min(128, k)) if flavor == "albef" else {}
-    white, black, adapters_cls, _, cfg = tsb.build(flavor, "base", **cfg_kw)
+    assert (rec["white_seed"], rec["black_seed"]) == (3, 4)          # tsb.build's seeds: one model pair per flavor
+    white_gpu, black_gpu, adapters_cls, cfg = _models(flavor, k, dev)
     shape = rec["shape"]
     ids, masks, att, tasks, _, images, eta = tsb.make_samples(flavor, cfg, n=n_all, seed=rec["seed"],
                                                              words=tuple(shape["words"]), max_att=shape["max_att"],
                                                              text_len=shape["text_len"])
     proposals = [[(int(p), [int(v) for v in vs]) for p, vs in row] for row in rec["proposals"]]
-    white_gpu, black_gpu = copy.deepcopy(white).to(dev), copy.deepcopy(black).to(dev)
-    del white, black
     sim = text_update.BagOfEmbeddingsSimilarity(seed=rec["sim_seed"])
     attack = BatchedVQAttack(adapters_cls(white_gpu), flavor, white_gpu.embedding_tables(),
                              AttackConfig(budget=rec["budget"], sanity_checks=True, sim_threshold=rec["sim_threshold"]),
@@ -98,7 +108,7 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
     id_rows = int((torch.cat(got_ids) != torch.tensor(rec["adv_text_ids"][:n])).any(dim=1).sum())
     print("{} base: n = {}{}, closed answer set of {}, oracle ASR {:.4f}, product ASR {:.4f}; {} success bits differ "
           "({:.2%}), {} adversarial answer indices differ, {} rows of substituted ids differ; oracle margins of the "
-          "differing samples: {}".format(flavor, n, "" if n == n_all else " (first {} of {})".format(n, n_all), k,
+          "differing samples: {}".format(flavor, n, "" if n == n_have else " (first {} of {})".format(n, n_have), k,
                                          float(np.mean(want_bits[:n])), float(np.mean(got_bits)), len(differ),
                                          len(differ) / n, len(ans_differ), id_rows,
                                          [round(margins[s], 5) for s in sorted(set(differ + ans_differ))]))
@@ -113,7 +123,7 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
         not_tied, [margins[s] for s in not_tied])
     assert len(differ) <= max(1, int(0.005 * n)), "{} of {} success bits differ: samples {}".format(len(differ), n, differ)
     assert 0 < sum(got_bits) < n
-    RESULTS[name] = dict(flavor=flavor, n=n, n_in_file=n_all, seed=rec["seed"], n_answers=k, want=want_bits[:n],
+    RESULTS[name] = dict(flavor=flavor, n=n, n_in_file=n_have, seed=rec["seed"], n_answers=k, want=want_bits[:n],
                          got=got_bits, margins=margins[:n], differ=differ)
 
 
@@ -159,6 +169,8 @@ def test_pooled_success_rate_within_half_a_percent():
         assert n < 200 or (abs(d) <= 0.005 and diff / n <= 0.005), flavor
         if FULL and n >= 2000:      # the interval, not just the point estimate, inside the north star's +-0.5 %
             assert abs(d) + half <= 0.005, "{}: difference {:+.4%} +- {:.4%}".format(flavor or "all", d, half)
+    _MODELS.clear()
+    torch.cuda.empty_cache()
     out = os.environ.get("VQA_ASR_REPORT")
     if out:
         os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
