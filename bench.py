@@ -81,25 +81,28 @@ def parse():
 
 
 def device_identity(index=None):
-    """A string that names the PHYSICAL device a rank computes on: the GPU's UUID where the runtime reports one, else
-    its PCI address.  Gathered over the ranks, the number of different strings is the number of GPUs that took part --
-    the evidence that an N-rank line was measured on N GPUs (``distinct_devices``)."""
+    """A string that names the PHYSICAL device a rank computes on: the GPU's UUID and its PCI address, whichever the
+    runtime reports (both when both).  Gathered over the ranks, the number of different strings is the number of GPUs that
+    took part -- the evidence that an N-rank line was measured on N GPUs (``distinct_devices``).  None when the runtime
+    reports neither (then nothing can be proven or refuted, and nothing is refused)."""
     if index is None or not torch.cuda.is_available():
         import socket
         return "host:{}".format(socket.gethostname())
     prop = torch.cuda.get_device_properties(index)
+    parts = []
     uuid = getattr(prop, "uuid", None)
-    if uuid is not None and str(uuid).strip("0-") != "":
-        return "uuid:{}".format(uuid)
-    return "pci:{:04x}:{:02x}:{:02x}".format(getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", index),
-                                             getattr(prop, "pci_device_id", 0))
+    if uuid is not None and str(uuid).replace("0", "").replace("-", "") != "":
+        parts.append("uuid:{}".format(uuid))
+    if all(hasattr(prop, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        parts.append("pci:{:04x}:{:02x}:{:02x}".format(prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id))
+    return "|".join(parts) if parts else None
 
 
 def gather_rank_records(record, identity, use_dist, coll_device):
     """Every rank's (float record, device identity) on every rank: two small all-gathers OUTSIDE the timed region.
     The identity travels as the two 63-bit halves of its SHA-1."""
     import hashlib
-    h = hashlib.sha1(identity.encode()).digest()
+    h = hashlib.sha1(identity.encode()).digest() if identity is not None else bytes(16)     # all zero: unknown
     ident = [int.from_bytes(h[:8], "big") >> 1, int.from_bytes(h[8:16], "big") >> 1]
     if not use_dist:
         return [list(record)], [tuple(ident)]
@@ -212,7 +215,7 @@ def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text
     n = args.sweep
     col = lambda j: [r[j] for r in records]                                  # noqa: E731
     seconds, n_local, n_batches, s_steps, g_steps, gather, n_dual = (col(j) for j in range(7))
-    distinct = len(set(idents))
+    distinct = count_distinct(idents)
     return {
         "metric": "adversarial_vqa_examples_per_sec", "value": None if dry else round(n * args.steps / dt, 4),
         "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,10 +250,15 @@ def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text
     }
 
 
+def count_distinct(idents):
+    """Number of different devices among the ranks' identities; None when a rank could not name its device."""
+    return None if any(i == (0, 0) for i in idents) else len(set(idents))
+
+
 def check_distinct(idents, world, backend):
-    if backend == "nccl" and len(set(idents)) != world:
-        raise SystemExit("bench.py: {} ranks ran on {} distinct GPU(s): refusing to print an N-GPU line".format(
-            world, len(set(idents))))
+    n = count_distinct(idents)
+    if backend == "nccl" and n is not None and n != world:
+        raise SystemExit("bench.py: {} ranks ran on {} distinct GPU(s): refusing to print an N-GPU line".format(world, n))
 
 
 def dry_run_sweep(args, world, rank):
@@ -797,6 +805,7 @@ def main():
             line = sweep_line(args, world, results, dt, records, idents, dist.get_backend() if use_dist else None,
                               flavor, text_len, cfg.image_size, gemms_tuned=bool(gemms_tuned))
             line["seconds"] = round(dt, 3)
+            line["device_rank0"] = identity
             print(json.dumps(line), flush=True)
         if use_dist:
             dist.barrier()
@@ -879,7 +888,8 @@ def main():
                        "mean_real_tokens": round(sum(n_words) / len(n_words) + 2, 2), "substitutable_words": args.joint,
                        "sharding": "independent batches per rank, all-gather of success bits"},
             "attack_success_rate": asr,
-            "distinct_devices": len(set(idents)),       # GPUs (by UUID / PCI address) the ranks of this line computed on
+            "device_rank0": identity,
+            "distinct_devices": count_distinct(idents), # GPUs (by UUID / PCI address) the ranks of this line computed on
             "tuned_gemms": ({"file": os.path.relpath(os.environ.get("VQA_TUNED_GEMMS", tuned_gemms.DEFAULT_FILE), ROOT),
                              **tuned_gemms.status()} if gemms_tuned else None),
             "collective": ({"backend": dist.get_backend(), "world": dist.get_world_size(),

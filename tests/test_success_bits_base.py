@@ -42,7 +42,7 @@ FIXTURES = [("asr_base_vlmo.json", "vlmo"), ("asr_base_albef.json", "albef")]
 TIE = 1e-3          # oracle decision margin (gap between the victim's two leading answers) below which a sample is a tie
 RESULTS = {}        # fixture -> dict(flavor, n, want bits, got bits, margins, sample ids), for the pooled test
 FULL = os.environ.get("VQA_ASR_FULL", "") not in ("", "0")
-SUBSET = dict(vlmo=32, albef=16)     # driver-run suite: the first K samples of every fixture file
+SUBSET = dict(vlmo=64, albef=32)     # driver-run suite: the first K samples of every fixture file
 _MODELS = {}        # (flavor, answer-set size of the ALBEF victim) -> (white on the GPU, black on the GPU, adapters, cfg)
 
 
