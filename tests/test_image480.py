@@ -106,6 +106,34 @@ def test_vlmo_base_480px_image_pgd_losses_match_cpu_oracle():
     np.testing.assert_allclose(res.loss_lists[0], losses, rtol=1e-4)
 
 
+def test_vlmo_base_480px_full_40_step_attack_matches_cpu_oracle():
+    """The reference's call at the reference's resolution with the reference's budget: 40 PGD steps at 480 px (941 tokens on
+    the oracle side, 910 after the padding trim on the device).  Tolerances of a complete attack: >= 99 % of the pixels
+    bit-identical, |dev| <= 4 eps_iter, mean |dev| <= 1e-4, losses 1e-4 relative."""
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import VlmoRefAdapters
+    from tests.test_fullsize_parity import _compare as compare_full
+    from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_base
+    steps = 40
+    cpu_model = FrozenVlmo(vlmo_base(image_size=480), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, img, eta = _inputs([7], 40, seed=14)
+    attack = BatchedVQAttack(VlmoAttackAdapters(gpu_model), "vlmo", gpu_model.embedding_tables(),
+                             AttackConfig(budget=steps, sanity_checks=True))
+    res = attack.attack_batch(img.to(DEV), ids.to(DEV), masks.to(DEV), torch.zeros_like(ids, dtype=torch.bool).to(DEV),
+                              init_eta=eta.to(DEV))
+    ad = VlmoRefAdapters(cpu_model, ids, masks)
+    with torch.enable_grad():
+        adv, losses = oracle.projected_gradient_descent(ad.pgd_attack, img, EPS, EPS_ITER, steps, np.inf, clip_min=-1,
+                                                        clip_max=1, y=ad.gen_ori_feats(img), ori_x=img, time=0, ls=1,
+                                                        flavor="vlmo", init_eta=eta)
+    same = compare_full(res.adv_images[0].cpu(), adv[0].detach(), steps, full_attack=True)
+    print("VLMO-base 480 px, 40 steps: {:.3%} of the pixels bit-identical to the CPU oracle".format(same))
+    assert len(res.loss_lists[0]) == steps
+    np.testing.assert_allclose(res.loss_lists[0], losses, rtol=1e-4)
+
+
 def test_albef_base_480px_attack_matches_cpu_oracle():
     """ALBEF-base at its configured ``image_res: 480``: ViT over 901 tokens, six fusion layers whose text queries attend
     901 image keys; 8 steps, batch 2 with a padded second question, against the per-sample oracle."""

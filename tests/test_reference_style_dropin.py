@@ -23,19 +23,22 @@ DEV = torch.device("cuda", 0)
 EPS, EPS_ITER = 0.125, 0.01
 
 
-def _dropin_pgd(flavor):
+def _dropin_pgd(flavor, module="projected_gradient_descent.py"):
     """``projected_gradient_descent`` of the FILE a switched driver imports:
     ``<repo>/vqattack_amd/dropin/<flavor>/cleverhans/torch/attacks/projected_gradient_descent.py`` (executed from its path;
     both flavors' packages are named ``cleverhans``, so they cannot both sit on sys.path of one test process)."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "vqattack_amd", "dropin", flavor, "cleverhans", "torch", "attacks",
-                        "projected_gradient_descent.py")
-    spec = importlib.util.spec_from_file_location("dropin_{}_pgd".format(flavor), path)
+    path = os.path.join(root, "vqattack_amd", "dropin", flavor, "cleverhans", "torch", "attacks", module)
+    spec = importlib.util.spec_from_file_location("dropin_{}_{}".format(flavor, os.path.basename(path)[:-3]), path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.projected_gradient_descent
+
+
+def _dropin_pgd_vl(flavor):
+    return _dropin_pgd(flavor, "projected_gradient_descent_vl.py")
 
 
 def _question(n_words, text_len, seed):
@@ -70,9 +73,9 @@ def test_vlmo_base_reference_style_closure_through_the_dropin_module(image_size)
     me = reference_closures("vlmo", gpu_model, dict(text_ids=ids.to(DEV), text_masks=masks.to(DEV)))
     y = me.Gen_ori_feats(img.to(DEV))
     assert [tuple(t.shape) for t in y] == [(1, 768), (13, 768), (13, 9 + 577, 768)]           # packed plain tensors
-    with torch.enable_grad():
-        adv, losses = pgd(me.pgd_attack, start.to(DEV), EPS, EPS_ITER, steps, np.inf, -1, 1, y=y, time=1,
-                          ori_x=img.to(DEV), ls=1)
+    with torch.enable_grad():                          # vlmo_module.py:1973-1976: y=[None, tgt_feats, feats_list, None, None]
+        adv, losses = pgd(me.pgd_attack, start.to(DEV), EPS, EPS_ITER, steps, np.inf, clip_min=-1, clip_max=1,
+                          y=[None, y[1], y[2], None, None], time=1, ori_x=img.to(DEV), ls=1)
     # ---- the CPU oracle with the oracle's own restatement of the packing
     ad = VlmoRefAdapters(cpu_model, ids, masks)
     with torch.enable_grad():
@@ -109,3 +112,61 @@ def test_albef_base_reference_style_closure_through_the_dropin_module():
                                                               ori_x=img, time=1, ls=1, flavor="albef")
     _same(adv.cpu(), want.detach(), steps)
     np.testing.assert_allclose(losses, want_losses, rtol=1e-4)
+
+
+def test_vlmo_base_reference_style_dual_loss_and_text_probe_calls():
+    """The two other operator calls of the reference's block loop, in the reference's form, at VLMO-base size:
+      * dual loss (``old_alg == 0``): ``pgd.projected_gradient_descent([self.pgd_attack, self.pgd_mlm_attack], adv_img, 0.125,
+        0.01, int(iter / 2), np.inf, clip_min=-1, clip_max=1, y=[mlm_labels, tgt_feats, feats_list, None], time=ii,
+        ori_x=..., ls=0)`` (vlmo_module.py:2009-2012) -- the MLM closure returns DENSE logits (1, 40, 30522) for the
+        [MASK]-ed paraphrase, as the reference's does (:1448-1529);
+      * the text-gradient probe: ``pgd_vl.projected_gradient_descent(self.pgd_attack_vl, [adv_x, adv_text_embeds], 0.125, 0.01,
+        1, np.inf, ..., y=[None, tgt_feats, feats_list, None, None], time=1, ori_x=..., ls=1, attack_mask=attack_vector)``
+        (:1986-1996) -> (adv_x, text_embed_gradient (1, K, 768))."""
+    from oracle import cleverhans_cpu as oracle
+    from oracle.adapters_ref import VlmoRefAdapters
+    from tests.test_fullsize_parity import _dual_tasks
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, vlmo_base
+    cpu_model = FrozenVlmo(vlmo_base(384), seed=0)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    ids, masks, g = _question(6, 40, seed=8)
+    img = torch.empty(1, 3, 384, 384).uniform_(-1, 1, generator=g)
+    start = torch.clamp(img + torch.empty_like(img).uniform_(-EPS, EPS, generator=g), -1, 1)
+    tasks, _ = _dual_tasks("vlmo", ids, 40)
+    t = tasks[0]
+    ids_mlm, mask_mlm = torch.tensor([t.text_ids_mlm]), torch.tensor([t.text_mask_mlm])
+    labels = torch.tensor([t.mlm_labels])                                   # (1, 40), -100 except the [MASK]-ed piece
+    assert ids_mlm.shape == (1, 40) and int((labels != -100).sum()) >= 1
+    me = reference_closures("vlmo", gpu_model, dict(text_ids=ids.to(DEV), text_masks=masks.to(DEV),
+                                                    text_ids_mlm=ids_mlm.to(DEV), text_mask_mlm=mask_mlm.to(DEV)))
+    y = me.Gen_ori_feats(img.to(DEV))
+    ad = VlmoRefAdapters(cpu_model, ids, masks, ids_mlm, mask_mlm)
+    tgt = ad.gen_ori_feats(img)
+    # ---- dual loss: 3 iterations = 6 white-box gradient steps, 6 losses
+    n_dual = 3
+    with torch.enable_grad():
+        adv, losses = _dropin_pgd("vlmo")([me.pgd_attack, me.pgd_mlm_attack], start.to(DEV), EPS, EPS_ITER, n_dual, np.inf,
+                                         clip_min=-1, clip_max=1, y=[labels.to(DEV), y[1], y[2], None], time=1,
+                                         ori_x=img.to(DEV), ls=0)
+        want, want_losses = oracle.projected_gradient_descent([ad.pgd_attack, ad.pgd_mlm_attack], start, EPS, EPS_ITER,
+                                                              n_dual, np.inf, clip_min=-1, clip_max=1,
+                                                              y=[labels, tgt[1], tgt[2], None], ori_x=img, time=1, ls=0,
+                                                              flavor="vlmo")
+    _same(adv.cpu(), want.detach(), 2 * n_dual)
+    assert len(losses) == 2 * n_dual
+    np.testing.assert_allclose(losses, want_losses, rtol=2e-4)
+    # ---- the probe: one step on [image, text embeddings], gradient rows of the attackable positions handed back
+    attack_vector = [2, 4]
+    emb_gpu, emb_cpu = gpu_model.text_embeddings(ids.to(DEV)), cpu_model.text_embeddings(ids)
+    with torch.enable_grad():
+        adv2, tgrad = _dropin_pgd_vl("vlmo")(me.pgd_attack_vl, [adv.detach(), emb_gpu], EPS, EPS_ITER, 1, np.inf, clip_min=-1,
+                                             clip_max=1, y=[None, y[1], y[2], None, None], time=1, ori_x=img.to(DEV), ls=1,
+                                             attack_mask=attack_vector)
+        want2, want_tgrad = oracle.projected_gradient_descent_vl(ad.pgd_attack_vl, [adv.detach().cpu(), emb_cpu], EPS,
+                                                                 EPS_ITER, 1, np.inf, clip_min=-1, clip_max=1,
+                                                                 y=[None, tgt[1], tgt[2], None, None], ori_x=img, time=1,
+                                                                 ls=1, attack_mask=attack_vector, flavor="vlmo")
+    assert tuple(tgrad.shape) == (1, 2, 768)
+    _same(adv2.cpu(), want2.detach(), 1)
+    err = float((tgrad.cpu() - want_tgrad).abs().max())
+    assert err <= 2e-4 * float(want_tgrad.abs().max()), (err, float(want_tgrad.abs().max()))
