@@ -70,6 +70,9 @@ def main():
                     help="attack and score only the first UPTO samples of the --n sample set (the inputs are still those of "
                          "the n-sample draw: the random start of sample s depends on n); the fixture records n_scored. "
                          "Turns an interrupted run's cache into a usable fixture")
+    ap.add_argument("--time-budget", type=float, default=None,
+                    help="seconds: stop attacking further samples after this long and write the fixture for the prefix "
+                         "done so far (n_scored), so that a run with a hard wall-clock limit always leaves a usable file")
     ap.add_argument("--sizes", default=None,
                     help="comma list of closed-answer-set sizes to score (default: CANDIDATE_SIZES); the attack results are "
                          "cached, so re-scoring with other sizes costs minutes")
@@ -109,6 +112,12 @@ def main():
     last_losses = []
     with tsb.oracle_text_len(flavor, ids.shape[1]):
         for s in range(args.n):
+            if args.time_budget and time.perf_counter() - t0 > args.time_budget:
+                log("time budget reached after {} samples".format(s))
+                args.n = s
+                ids, masks, att, images, eta = ids[:s], masks[:s], att[:s], images[:s], eta[:s]
+                oracle_tasks, proposals, adv_ids = oracle_tasks[:s], proposals[:s], adv_ids[:s]
+                break
             path = os.path.join(cache, "s{:04d}.npz".format(s))
             n = int(masks[s].sum()) if flavor == "albef" else ids.shape[1]
             if os.path.exists(path):

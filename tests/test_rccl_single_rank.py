@@ -90,6 +90,25 @@ def test_bench_single_rank_over_rccl(tmp_path):
     assert coll is not None and coll["backend"] == "nccl" and coll["world"] == 1
     assert coll["tensor_device"].startswith("cuda") and coll["calls"] == 1      # ONE all-gather of the bits, on a device tensor
     assert rec["attack_success_rate"] is not None
+    assert rec["distinct_devices"] == 1 and rec["device_rank0"]         # gathered through RCCL as two int64 words
+
+
+def test_bench_sweep_single_rank_over_rccl(tmp_path):
+    """``bench.py --sweep`` (BASELINE configs[3]'s form) as a 1-rank torchrun job: the sweep's two all-gathers (success bits,
+    adversarial text) and the per-rank record / device-identity gathers run on DEVICE tensors through RCCL; under RCCL the
+    number of distinct devices must equal the number of ranks (here 1 == 1), and the line names rank 0's GPU."""
+    out = str(tmp_path / "bench_sweep.out")
+    argv = ["--gpus", "1", "--sweep", "40", "--warmup", "1", "--model", "vlmo_tiny", "--batch", "16", "--pgd-steps", "8"]
+    code = _run(_bench_rank, (_free_port(), out, argv))
+    text = open(out).read()
+    assert code == 0, text[-2000:]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 1 and rec["config"]["n_samples"] == 40
+    assert rec["collective"] == {"backend": "nccl", "world": 1, "calls": 2}
+    assert rec["distinct_devices"] == 1 and rec["device_rank0"] and ("uuid:" in rec["device_rank0"] or "pci:" in rec["device_rank0"])
+    assert rec["per_rank"]["samples"] == [40] and rec["per_rank"]["n_batches"] == [3] and rec["value"] > 0
 
 
 def test_entry_run_single_rank_over_rccl(tmp_path):

@@ -125,6 +125,11 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
     assert 0 < sum(got_bits) < n
     RESULTS[name] = dict(flavor=flavor, n=n, n_in_file=n_have, seed=rec["seed"], n_answers=k, want=want_bits[:n],
                          got=got_bits, margins=margins[:n], differ=differ)
+    if os.environ.get("VQA_ASR_SETS_LOG"):           # one line per set as it finishes (tools/asr_box_round.sh reads it)
+        with open(os.environ["VQA_ASR_SETS_LOG"], "a") as f:
+            f.write(json.dumps(dict(fixture=name, flavor=flavor, n=n, oracle_asr=sum(want_bits[:n]) / n,
+                                    product_asr=sum(got_bits) / n, differ=differ,
+                                    margins=[margins[s] for s in differ])) + "\n")
 
 
 def paired_difference(want, got):

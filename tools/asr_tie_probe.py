@@ -77,7 +77,7 @@ def main():
     batch = 50 if flavor == "vlmo" else 32              # the slices of tests/test_success_bits_base.py (full mode)
     for s in [int(v) for v in args.samples.split(",")]:
         lo = s // batch * batch
-        sl = slice(lo, lo + batch)
+        sl = slice(lo, min(lo + batch, rec.get("n_scored", n)))      # the test's slice (a partial set ends at n_scored)
         res = attack.attack_mixed(images[sl].to(dev), ids[sl].to(dev), masks[sl].to(dev), att[sl].to(dev),
                                   init_eta=eta[sl].to(dev), proposals=proposals[sl], tasks=tasks[sl])
         prod_img, prod_ids = res.adv_images[s - lo:s - lo + 1].cpu(), res.adv_text_ids[s - lo:s - lo + 1].cpu()
