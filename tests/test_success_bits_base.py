@@ -9,8 +9,9 @@ to the adversarial pairs, the substituted token ids, the success bits and the de
 runs -- the batched joint attack on the MI355X (``attack_mixed``: HIP operators, mixed schedules and loss modes in one
 batch) and the batched black-box scorer -- on the same regenerated inputs, so no GPU time is spent waiting for the CPU.
 
-Two modes.  The driver-run suite (default) attacks a FIXED SUBSET -- the first ``SUBSET[flavor]`` samples of every file,
-no selection by outcome -- to stay inside the suite's time budget.  ``VQA_ASR_FULL=1`` attacks every sample of every
+Two modes.  The driver-run suite (default) attacks a FIXED SUBSET -- the first ``SUBSET[flavor]`` samples of every file
+(``SUBSET_SMALL[flavor]`` of a draw with fewer than 100 samples), no selection by outcome -- to stay inside the suite's
+time budget.  ``VQA_ASR_FULL=1`` attacks every sample of every
 file (the pool the north star's "+-0.5 % on the same 5k pairs" is judged on; run once per round through gpurun, the
 per-sample report written to ``$VQA_ASR_REPORT`` is tracked under ``profiles/``).
 
@@ -42,7 +43,8 @@ FIXTURES = [("asr_base_vlmo.json", "vlmo"), ("asr_base_albef.json", "albef")]
 TIE = 1e-3          # oracle decision margin (gap between the victim's two leading answers) below which a sample is a tie
 RESULTS = {}        # fixture -> dict(flavor, n, want bits, got bits, margins, sample ids), for the pooled test
 FULL = os.environ.get("VQA_ASR_FULL", "") not in ("", "0")
-SUBSET = dict(vlmo=64, albef=32)     # driver-run suite: the first K samples of every fixture file
+SUBSET = dict(vlmo=64, albef=32)     # driver-run suite: the first K samples of every fixture file ...
+SUBSET_SMALL = dict(vlmo=16, albef=8)    # ... of the many small draws (< 100 samples, tools/asr_box_round.sh): one batch each
 _MODELS = {}        # (flavor, answer-set size of the ALBEF victim) -> (white on the GPU, black on the GPU, adapters, cfg)
 
 
@@ -73,10 +75,13 @@ def test_base_size_success_bits_match_the_recorded_oracle(name, flavor):
     from vqattack_amd.attack import text_update
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
     rec = _fixture(name, flavor)
-    assert rec["size"] == "base" and 0.3 <= rec["oracle_asr"] <= 0.7, "the fixture must be informative"
+    # informative: both outcomes occur often.  The generator picks the answer-set size whose oracle ASR lies inside
+    # 0.3 .. 0.7; a draw of a few dozen samples may have no such size (the rate moves in steps of 1 / n with n and jumps
+    # between neighbouring answer-set sizes): then the size closest to 0.5, which must still lie inside 0.2 .. 0.8
+    assert rec["size"] == "base" and 0.2 <= rec["oracle_asr"] <= 0.8, "the fixture must be informative"
     n_all, k = rec["n"], rec["n_answers"]               # n_all: size of the seeded draw that regenerates the inputs
     n_have = rec.get("n_scored", n_all)                 # ... of which the oracle attacked and scored a prefix
-    n = n_have if FULL else min(n_have, SUBSET[flavor])
+    n = n_have if FULL else min(n_have, (SUBSET if n_have >= 100 else SUBSET_SMALL)[flavor])
     dev = torch.device("cuda", 0)
     assert (rec["white_seed"], rec["black_seed"]) == (3, 4)          # tsb.build's seeds: one model pair per flavor
     white_gpu, black_gpu, adapters_cls, cfg = _models(flavor, k, dev)
@@ -150,8 +155,9 @@ def test_pooled_success_rate_within_half_a_percent():
     missing = [f[0] for f in FIXTURES if f[0] not in RESULTS]
     if missing:
         pytest.skip("needs the per-set tests of this module to have run first (missing: {})".format(missing))
-    report = dict(mode="full" if FULL else "subset (first {} VLMO / {} ALBEF samples of every file)".format(
-        SUBSET["vlmo"], SUBSET["albef"]), tie_margin=TIE, sets={}, pooled={})
+    report = dict(mode="full" if FULL else "subset (first {} VLMO / {} ALBEF samples of every file, {} / {} of a draw of "
+                  "fewer than 100)".format(SUBSET["vlmo"], SUBSET["albef"], SUBSET_SMALL["vlmo"], SUBSET_SMALL["albef"]),
+                  tie_margin=TIE, sets={}, pooled={})
     for name, r in RESULTS.items():
         report["sets"][name] = dict(flavor=r["flavor"], n=r["n"], n_in_file=r["n_in_file"], seed=r["seed"],
                                     n_answers=r["n_answers"], oracle_asr=sum(r["want"]) / r["n"],
