@@ -328,7 +328,7 @@ def build_models(args, cfg, device):
 # below holds, per phase of tools/pmc_step.py, the launch SHAPE it ran and FETCH_SIZE x 2 (gfx950 correction) +
 # WRITE_SIZE per launch and kernel (tools/pmc_run.sh on the shipped build).  A figure is copied into the line -- as
 # `traffic` with `traffic_kind: "recorded"` -- only when the run's launch has exactly the recorded shape.
-PMC_TRAFFIC = "profiles/r04/pmc_traffic.json"
+PMC_TRAFFIC = "profiles/r05/pmc_traffic.json"
 
 
 def recorded_traffic(kernel, shape):
