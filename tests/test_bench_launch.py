@@ -72,6 +72,26 @@ def test_sweep_mode_single_process():
     assert rec["per_rank"]["n_batches"] == [5]
 
 
+def test_distinct_device_accounting():
+    """``distinct_devices``: the number of different device identities (SHA-1 halves of GPU UUID + PCI address) gathered
+    over the ranks; unknown (a rank could not name its device) is reported as null and never refused; under RCCL a line
+    whose ranks shared a GPU is refused, the gloo rehearsal (several ranks on one GPU on purpose) is not."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    a, b = (11, 12), (21, 22)
+    assert bench.count_distinct([a, b, a]) == 2 and bench.count_distinct([a]) == 1
+    assert bench.count_distinct([a, (0, 0)]) is None
+    bench.check_distinct([a, b], 2, "nccl")
+    bench.check_distinct([a, a], 2, "gloo")
+    bench.check_distinct([a, (0, 0)], 2, "nccl")
+    with pytest.raises(SystemExit):
+        bench.check_distinct([a, a], 2, "nccl")
+    recs, ids = bench.gather_rank_records([1.0, 2.0], "uuid:x|pci:0000:01:00", False, None)
+    assert recs == [[1.0, 2.0]] and len(ids) == 1 and ids[0] != (0, 0)
+    assert bench.gather_rank_records([0.0], None, False, None)[1] == [(0, 0)]
+
+
 def test_world_size_mismatch_exits_non_zero():
     p = _run(["--gpus", "2", "--dry-run"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
              MASTER_PORT="29999")
