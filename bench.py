@@ -48,7 +48,7 @@ def parse():
                     help="BASELINE configs[3] as written: a FIXED seeded set of N_SAMPLES joint attacks (mixed schedules, "
                          "every --dual-every-th sample dual-loss) sharded rank::world through attack/sweep.run_sweep -- "
                          "strong scaling: examples/s = N_SAMPLES / max-over-ranks seconds")
-    ap.add_argument("--dual-every", type=int, default=4, help="with --sweep: every n-th sample is a dual-loss sample")
+    ap.add_argument("--dual-every", type=int, default=4, help="with --sweep: one sample in n is a dual-loss sample (spread over the set by a seeded permutation)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--pgd-steps", type=int, default=40)
     ap.add_argument("--image-size", type=int, default=384)
@@ -223,8 +223,8 @@ def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "{} VQAttack sweep (BASELINE configs[3]{}): a FIXED seeded set of {} (image, question) pairs "
                                "sharded rank::world over {} rank(s), joint image+text attack with each sample's own block "
-                               "schedule (40 image steps + one probe per substitutable word, 4..12 words), every {}th "
-                               "sample dual-loss, mixed batches of <= {} per rank sorted by schedule length, {}x{} images, "
+                               "schedule (40 image steps + one probe per substitutable word, 4..12 words), one sample in {} "
+                               "dual-loss, mixed batches of <= {} per rank sorted by schedule length, {}x{} images, "
                                "black-box scoring, ONE all-gather of success bits + ONE of the adversarial text; one step "
                                "= one pass over the whole set".format(
                                    args.model, "" if (args.model == "vlmo_base" and n >= 5000 and image_size == 384
