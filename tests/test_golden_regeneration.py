@@ -42,3 +42,13 @@ def test_text_golden_reproduces_from_the_reference(tmp_path):
     _same_npz(npz, os.path.join(GOLD, "text_golden.npz"))
     with open(js) as fa, open(os.path.join(GOLD, "text_golden.json")) as fb:
         assert json.load(fa) == json.load(fb)
+
+
+def test_encoder_golden_reproduces_from_the_reference(tmp_path):
+    """The white-box encoder fixtures: the reference's Mlp / Attention / Block / MultiWayTransformer / VisionTransformer /
+    BertEncoder classes and the VLMo attack closures, executed from source again, give the committed arrays."""
+    npz, js = str(tmp_path / "encoder_golden.npz"), str(tmp_path / "encoder_golden.json")
+    _run("from tests.golden import make_encoder_golden as m; m.main({!r}, {!r})".format(npz, js), tmp_path)
+    _same_npz(npz, os.path.join(GOLD, "encoder_golden.npz"))
+    with open(js) as fa, open(os.path.join(GOLD, "encoder_golden.json")) as fb:
+        assert json.load(fa) == json.load(fb)

@@ -212,6 +212,23 @@ class FrozenAlbef(nn.Module):
                     p.copy_(w + drift * rms * torch.empty(w.shape).normal_(generator=g))
         return black
 
+    # ---- reference checkpoints ------------------------------------------------------------------------------
+    def load_reference_state_dict(self, state_dict, strict=True):
+        """Fill this model from a state dict of the reference's ``ALBEF_pre`` (white box, adv_attack.py:83-92) or
+        ``ALBEF`` VQA model (black box, :96-100): packed ViT ``qkv`` split into q / k / v, position table resampled
+        bicubically to this image size, HF BERT layer names mapped (``whitebox/checkpoint.py``)."""
+        from . import checkpoint
+        return checkpoint.load_albef(self, state_dict, strict=strict)
+
+    def set_answer_list(self, answer_ids):
+        """Replace the synthetic answer list by tokenised answers (n, L) int64: ``[BOS] pieces [SEP] pad...`` rows as
+        ``tokenizer(answer_list, padding='longest')`` with the first id overwritten by ``bos`` produces them
+        (adv_attack.py:407-409, model_vqa.py:149-155)."""
+        if not self.has_vqa:
+            raise RuntimeError("this FrozenAlbef was built without the VQA decoder")
+        self.answer_ids = answer_ids.to(self.answer_ids.device, torch.long).contiguous()
+        self.cfg.n_answers, self.cfg.answer_len = int(answer_ids.shape[0]), int(answer_ids.shape[1])
+
     # ---- pieces ---------------------------------------------------------------------------------------------
     def visual_encoder(self, image):
         """``image``: (B, 3, H, W), or already patch-major (B, n_patches, 3*p*p) (``vqattack_amd.layout``)."""

@@ -48,6 +48,11 @@ class VlmoConfig:
     # "pretrain_init": the reference's initialisation before any training (trunc-normal 0.02, layer scale 0.1) -- with
     # it every output is dominated by the token embeddings and no perturbation ever changes a black-box answer.
     weights: str = "trained_like"
+    # BertEmbeddings adds its absolute position table only for position_embedding_type "absolute"; the reference builds
+    # VLMo-base / -large with "rel_pos" (vlmo_module.py:216; transformers==4.8.1 BertEmbeddings, the code vendored at
+    # ALBEF_attack/models/xbert.py:210-212), so a reference checkpoint runs with False (whitebox/checkpoint.py sets it).
+    # True is the synthetic default the committed fixtures and recorded numbers were made with.
+    text_abs_pos: bool = True
 
     @property
     def n_patches(self):
@@ -162,6 +167,9 @@ class FrozenVlmo(nn.Module):
         self.mlm_dense = nn.Linear(d, d)
         self.mlm_ln = nn.LayerNorm(d, eps=cfg.bert_ln_eps)
         self.mlm_bias = nn.Parameter(torch.zeros(cfg.vocab))
+        # MLM decoder: tied to the word embeddings for the synthetic weights; the reference's ``MLMHead(bert_config)``
+        # (vlmo_module.py:232, heads.py:40-47) has its OWN (V, D) matrix, which ``set_mlm_decoder`` installs
+        self.register_parameter("mlm_decoder", None)
         ntok = cfg.max_text_len + cfg.n_image_tokens
         # relative position bias, one (heads, T+N, T+N) slab per layer (vlmo_module.py:807-814); frozen -> precomputed
         self.register_buffer("rel_pos_bias", torch.zeros(cfg.depth, cfg.heads, ntok, ntok), persistent=False)
@@ -230,17 +238,45 @@ class FrozenVlmo(nn.Module):
             black.rel_pos_bias.copy_(white.rel_pos_bias.detach().cpu())
         return black
 
+    # ---- reference checkpoints ------------------------------------------------------------------------------
+    def set_mlm_decoder(self, weight):
+        """Untie the MLM decoder from the word embeddings (``weight`` (V, D)); None ties it again."""
+        if weight is None:
+            self.mlm_decoder = None
+            return
+        ref = self.word_embeddings.weight
+        self.mlm_decoder = nn.Parameter(weight.detach().to(ref.device, ref.dtype).clone(), requires_grad=False)
+
+    def load_reference_state_dict(self, state_dict, strict=True, max_text_len_of_initckpt=None):
+        """Fill this model from a state dict of the reference's ``VLMo`` module (``transformer.blocks.N.attn.q_bias``,
+        ``relative_position_bias_table``, ``text_embeddings.*``, ...): ``whitebox/checkpoint.py``.  The configuration
+        must already have the checkpoint's widths (``checkpoint.vlmo_from_reference`` derives it); the text embeddings
+        switch to the reference's "rel_pos" form (no absolute position table added)."""
+        from . import checkpoint
+        out = checkpoint.load_vlmo(self, state_dict, strict=strict, max_text_len_of_initckpt=max_text_len_of_initckpt)
+        self.cfg.text_abs_pos = False
+        self._zero_pos = None
+        return out
+
     # ---- embeddings -----------------------------------------------------------------------------------------
     def text_embeddings(self, ids):
-        """BERT embeddings (word + type 0, then + position, LayerNorm); eval mode -> no dropout."""
+        """BERT embeddings (word + type 0, then + position when ``cfg.text_abs_pos``, LayerNorm); eval mode -> no
+        dropout."""
         length = ids.shape[1]
         e = self.word_embeddings(ids) + self.bert_type_embeddings.weight[0]
-        e = e + self.position_embeddings.weight[:length].unsqueeze(0)
+        if self.cfg.text_abs_pos:
+            e = e + self.position_embeddings.weight[:length].unsqueeze(0)
         return self.bert_ln(e)
 
     def embedding_tables(self):
         """Raw tables for the candidate-scoring kernel (``ops.cand_dir_sim``)."""
-        return dict(word=self.word_embeddings.weight, pos=self.position_embeddings.weight,
+        pos = self.position_embeddings.weight
+        if not self.cfg.text_abs_pos:                    # the kernels add a position row: hand them exact zeros
+            z = getattr(self, "_zero_pos", None)
+            if z is None or z.device != pos.device or z.shape != pos.shape:
+                z = self._zero_pos = torch.zeros_like(pos)
+            pos = z
+        return dict(word=self.word_embeddings.weight, pos=pos,
                     type_emb=self.bert_type_embeddings.weight, gamma=self.bert_ln.weight, beta=self.bert_ln.bias,
                     ln_eps=self.cfg.bert_ln_eps)
 
@@ -330,7 +366,7 @@ class FrozenVlmo(nn.Module):
 
     def mlm_score(self, text_states):
         h = self.mlm_ln(F.gelu(self.mlm_dense(text_states)))
-        return F.linear(h, self.word_embeddings.weight, self.mlm_bias)
+        return F.linear(h, self.word_embeddings.weight if self.mlm_decoder is None else self.mlm_decoder, self.mlm_bias)
 
     def pooled(self, states):
         return torch.tanh(self.pooler(states[:, 0]))
