@@ -80,9 +80,19 @@ def listing_of(state_dict):
     return [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in state_dict.items()]
 
 
+def checksum(t):
+    """[sum of the elements' bit patterns, position-weighted sum of them] in wrapping int64 arithmetic: exact, and
+    independent of the reduction order (a float sum differs in its last bit between hosts with other thread counts)."""
+    if t.dtype != torch.float32:
+        bits = t.reshape(-1).to(torch.int64)
+    else:
+        bits = t.contiguous().reshape(-1).view(torch.int32).to(torch.int64)
+    weight = torch.arange(bits.numel(), dtype=torch.int64) % 251 + 1
+    return [int(bits.sum()), int((bits * weight).sum())]
+
+
 def checksums(state_dict):
-    """Per-tensor float64 (sum, sum of squares) -- enough to tell a regenerated state dict from a different one."""
-    return {k: [float(v.double().sum()), float(v.double().pow(2).sum())] for k, v in state_dict.items()}
+    return {k: checksum(v) for k, v in state_dict.items()}
 
 
 def case_inputs(name, case, flavor):
