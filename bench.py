@@ -48,6 +48,17 @@ def parse():
                     help="BASELINE configs[3] as written: a FIXED seeded set of N_SAMPLES joint attacks (mixed schedules, "
                          "every --dual-every-th sample dual-loss) sharded rank::world through attack/sweep.run_sweep -- "
                          "strong scaling: examples/s = N_SAMPLES / max-over-ranks seconds")
+    ap.add_argument("--from-uint8", action="store_true",
+                    help="with --sweep: the input and output steps either side of the attack INSIDE the timed region -- "
+                         "seeded 8-bit 480x640 host images through the file pipeline's device path (pinned upload, "
+                         "Pillow-exact resize + normalise, csrc/image.hip; ALBEF_attack/dataset/__init__.py:35-39) and "
+                         "every adversarial image written as <qid>.pt (adv_attack.py:714) to a scratch directory; the "
+                         "line reports their share")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="W",
+                    help="with --sweep on ONE GPU: run the W rank::W shards of the set one after another in this process "
+                         "and report per-shard seconds / passes / steps and max/mean over shards -- a PREDICTION of the "
+                         "W-GPU strong-scaling efficiency from the shard imbalance, labelled 'strong-emulated', never a "
+                         "scaling measurement")
     ap.add_argument("--dual-every", type=int, default=4, help="with --sweep: one sample in n is a dual-loss sample (spread over the set by a seeded permutation)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--pgd-steps", type=int, default=40)
@@ -122,6 +133,47 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes", dev="/dev/dri"):
+    """GPUs this process could open, counted WITHOUT the HIP / HSA runtime (no ``torch.cuda`` call, no ``/dev/kfd``
+    descriptor: ``torch.cuda.device_count()`` falls back to ``hipGetDeviceCount`` whenever amdsmi does not initialise,
+    and a launcher that has initialised HIP must not start GPU children on these hosts).  Read from the KFD topology the
+    kernel publishes: a node is a GPU when its ``simd_count`` is positive; it is THIS job's when its properties are
+    readable (a device cgroup hides the other tenants' nodes: EPERM) and its render node ``/dev/dri/renderD<minor>`` is
+    accessible -- the test the ROCr runtime itself applies when it enumerates agents.  ``*_VISIBLE_DEVICES`` lists cap
+    the count.  No KFD topology at all: 0 (no ROCm device can exist).  None: the topology is there but nothing in it
+    could be read -- unknown; the caller then skips its pre-check (the ranks' ``check_distinct`` still refuses a run
+    whose ranks shared a device)."""
+    if not os.path.isdir(sysfs):
+        return 0
+    count, readable = 0, 0
+    for node in sorted(os.listdir(sysfs)):
+        try:
+            with open(os.path.join(sysfs, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        readable += 1
+        if int(props.get("simd_count", "0")) <= 0:
+            continue                                                     # a CPU node
+        minor = int(props.get("drm_render_minor", "-1"))
+        if minor >= 0 and os.path.isdir(dev) and not os.access(os.path.join(dev, "renderD{}".format(minor)),
+                                                               os.R_OK | os.W_OK):
+            continue
+        count += 1
+    if readable == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        listed = os.environ.get(var, "").strip()
+        if listed:
+            entries = []
+            for e in listed.split(","):                                  # the runtimes stop at the first invalid entry
+                if e.strip() in ("", "-1"):
+                    break
+                entries.append(e)
+            count = min(count, len(entries))
+    return count
+
+
 def launch_ranks(args):
     """``--gpus N`` (N > 1) without a launcher environment: start the N ranks as CHILD processes under
     ``torch.distributed.run`` -- before this process has made any GPU call (it never makes one: a process that has
@@ -129,8 +181,8 @@ def launch_ranks(args):
     the JSON line) and return the launcher's exit code: a failed rank fails the whole run."""
     import subprocess
     if not args.dry_run and os.environ.get("VQA_DIST_BACKEND", "nccl") == "nccl":
-        have = torch.cuda.device_count()               # counting devices does not initialise the runtime
-        if have < args.gpus:
+        have = visible_gpu_count()                     # sysfs only: this process never touches the GPU runtime
+        if have is not None and have < args.gpus:
             raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible; refusing to run fewer ranks under an "
                              "N-GPU label".format(args.gpus, have))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -215,6 +267,8 @@ def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text
     n = args.sweep
     col = lambda j: [r[j] for r in records]                                  # noqa: E731
     seconds, n_local, n_batches, s_steps, g_steps, gather, n_dual = (col(j) for j in range(7))
+    has_io = all(len(r) >= 10 for r in records)
+    io_in, io_blocked, io_writer = (col(j) for j in range(7, 10)) if has_io else ([0.0], [0.0], [0.0])
     distinct = count_distinct(idents)
     return {
         "metric": "adversarial_vqa_examples_per_sec", "value": None if dry else round(n * args.steps / dt, 4),
@@ -245,6 +299,19 @@ def sweep_line(args, world, res_list, dt, records, idents, backend, flavor, text
                       "note": "a rank's gather_seconds includes its wait for the slowest rank; the collective's own "
                               "latency is the minimum over ranks"},
         "all_gather_latency_ms": round(min(gather) * 1e3, 3),
+        # --from-uint8: 8-bit host images -> device resize + normalise before, <qid>.pt files after every batch, both inside
+        # seconds_attack.  input_seconds = host time of producing the image batches (decode wait + upload + kernel
+        # launches), of which input_blocked_seconds waited for pixels; writer_seconds = the wait for the asynchronous
+        # writer after the last batch (its copies and torch.save calls otherwise overlap the next batch's attack)
+        "input_pipeline": ({"source": "seeded uint8 (480, 640, 3) host arrays, one per sample", "resize": "Pillow-exact "
+                            "bicubic + ToTensor + Normalize(0.5, 0.5) on the device (csrc/image.hip)",
+                            "writer": "<qid>.pt (1, 3, H, W) fp32 per sample, scratch directory",
+                            "input_seconds": [round(v, 3) for v in io_in],
+                            "input_blocked_seconds": [round(v, 3) for v in io_blocked],
+                            "writer_seconds": [round(v, 3) for v in io_writer],
+                            "share_of_seconds_attack": round(max((a + w) / s for a, w, s in zip(io_in, io_writer, seconds)
+                                                                 if s > 0), 4)}
+                           if getattr(args, "from_uint8", False) and has_io else None),
         "tuned_gemms": gemms_tuned,
         "collective": ({"backend": backend, "world": world, "calls": res["collectives"]} if backend else None),
     }
@@ -738,14 +805,22 @@ def main():
     backend = os.environ.get("VQA_DIST_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     if use_dist:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a rank that never arrives must end the run with an error line well inside the caller's limit, not hang it
+        limit = datetime.timedelta(seconds=float(os.environ.get("VQA_DIST_TIMEOUT", "240")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_device = device if backend == "nccl" else torch.device("cpu")
+    identity = device_identity(dev_index)
+    # the devices are known now: a run whose ranks share a GPU under RCCL is refused BEFORE the warm-up and the timed
+    # region burn the lease (the gather after the run only collects the per-rank records)
+    _, idents = gather_rank_records([0.0], identity, use_dist, coll_device)
+    check_distinct(idents, world, backend if use_dist else None)
 
     from vqattack_amd.attack.asr import SuccessLedger
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
@@ -759,7 +834,6 @@ def main():
     attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(),
                              AttackConfig(budget=args.pgd_steps, random_start=True, sanity_checks=True,   # the reference's
                                           live_mlm_rows=not args.dense_mlm))   # call sites use the default True (adv_attack.py:633-636)
-    identity = device_identity(dev_index)
 
     def fence():
         torch.cuda.synchronize()
@@ -780,11 +854,72 @@ def main():
                 last[0] = time.perf_counter()
                 log("sweep: rank 0 has attacked {} of its {} samples".format(done, n_local))
 
-        def one_sweep(n, seed):
-            return run_sweep(flavor, white, black, adapters, n, args.batch, cfg.image_size, text_len, device, rank,
-                             world, joint=True, seed=seed, log_every=0,
-                             dual_every=args.dual_every, mixed=True, attack=sweep_attack, force_collective=use_dist,
-                             collective_device=coll_device, progress=progress)
+        scratch = None
+        if args.from_uint8:
+            import tempfile
+            scratch = tempfile.mkdtemp(prefix="vqa_bench_attack_dir_")
+
+        def make_source(n, seed):
+            from vqattack_amd.attack import dataset
+            kind = dataset.SyntheticUint8Pairs if args.from_uint8 else dataset.SyntheticPairs
+            return kind(n, text_len, cfg.image_size, flavor, seed=seed, joint=True, dual_every=args.dual_every)
+
+        def one_sweep(n, seed, source=None, as_rank=None):
+            r, w = (rank, world) if as_rank is None else (0, 1)
+            return run_sweep(flavor, white, black, adapters, n, args.batch, cfg.image_size, text_len, device, r,
+                             w, joint=True, seed=seed, log_every=0, save_dir=scratch,
+                             dual_every=args.dual_every, mixed=True, attack=sweep_attack,
+                             force_collective=use_dist and as_rank is None,
+                             collective_device=coll_device, progress=progress,
+                             source=source if source is not None else make_source(n, seed))
+
+        if args.emulate_world:
+            # ---- the W shards of the fixed set, one after another on this ONE GPU: a prediction, not a measurement
+            if world != 1:
+                raise SystemExit("--emulate-world runs in one process on one GPU (--gpus 1)")
+            from vqattack_amd.attack.asr import shard_indices
+            from vqattack_amd.attack.dataset import PairSubset
+            W = args.emulate_world
+            if args.warmup:
+                one_sweep(args.warmup * args.batch, seed=977)
+                log("warm-up sweep of {} samples done".format(args.warmup * args.batch))
+            full = make_source(args.sweep, 1)
+            fence()
+            t0 = time.perf_counter()
+            shards = []
+            for r in range(W):
+                shards.append(one_sweep(args.sweep, 1, source=PairSubset(full, shard_indices(args.sweep, r, W)), as_rank=r))
+                log("emulated rank {} of {}: {} samples in {:.1f} s".format(r, W, shards[-1]["n_local"], shards[-1]["seconds"]))
+            fence()
+            dt = time.perf_counter() - t0
+            full.close()
+            secs = [s["seconds"] for s in shards]
+            n_ok = sum(s["asr"] * s["n_total"] for s in shards)
+            keys = ("seconds", "n_total", "n_batches", "gradient_steps", "global_steps", "gather_seconds", "n_dual_local",
+                    "input_seconds", "input_blocked_seconds", "writer_seconds")
+            records = [[s[k] for k in keys] for s in shards]
+            line = sweep_line(args, W, [dict(shards[-1], asr=n_ok / args.sweep, collectives=0)], dt, records,
+                              [(1, 1)] * W, None, flavor, text_len, cfg.image_size, gemms_tuned=bool(gemms_tuned))
+            line.update({
+                "value": round(args.sweep / dt, 4), "ms_per_step": round(dt * 1e3, 2), "n_gpus": 1, "steps": 1,
+                "scaling": "strong-emulated", "seconds": round(dt, 3), "device_rank0": identity, "distinct_devices": 1,
+                "emulated": {
+                    "world": W,
+                    "what": "the {} rank::{} shards of the fixed set run ONE AFTER ANOTHER on one GPU; ranks of the real "
+                            "sweep exchange nothing before the final gathers, so a rank's time there is its shard's time "
+                            "here (same GPU model, no contention assumed).  A PREDICTION from the shard imbalance -- NOT a "
+                            "multi-GPU measurement; 'value' is this one GPU's throughput over the whole set".format(W, W),
+                    "shard_seconds_max": round(max(secs), 3), "shard_seconds_mean": round(sum(secs) / W, 3),
+                    "predicted_parallel_seconds": round(max(secs), 3),
+                    "predicted_value_at_world": round(args.sweep / max(secs), 4),
+                    "predicted_strong_scaling_efficiency": round(sum(secs) / W / max(secs), 4),
+                    "gather_seconds_single_process": [round(s["gather_seconds"], 5) for s in shards]}})
+            line["config"]["workload"] += " [emulated: {} shards in sequence on 1 GPU]".format(W)
+            print(json.dumps(line), flush=True)
+            if scratch:
+                import shutil
+                shutil.rmtree(scratch, ignore_errors=True)
+            return
         if args.warmup:
             one_sweep(args.warmup * args.batch * world, seed=977)
             log("warm-up sweep of {} samples done".format(args.warmup * args.batch * world))
@@ -797,10 +932,13 @@ def main():
             t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        keys = ("seconds", "n_local", "n_batches", "gradient_steps", "global_steps", "gather_seconds", "n_dual_local")
+        keys = ("seconds", "n_local", "n_batches", "gradient_steps", "global_steps", "gather_seconds", "n_dual_local",
+                "input_seconds", "input_blocked_seconds", "writer_seconds")
         record = [results[-1][k] if k in ("n_local", "n_dual_local") else sum(r[k] for r in results) for k in keys]
         records, idents = gather_rank_records(record, identity, use_dist, coll_device)
-        check_distinct(idents, world, backend if use_dist else None)
+        if scratch:
+            import shutil
+            shutil.rmtree(scratch, ignore_errors=True)
         if rank == 0:
             line = sweep_line(args, world, results, dt, records, idents, dist.get_backend() if use_dist else None,
                               flavor, text_len, cfg.image_size, gemms_tuned=bool(gemms_tuned))
@@ -859,8 +997,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     roof, roof_loss = timer.summary()
-    _, idents = gather_rank_records([0.0], identity, use_dist, coll_device)
-    check_distinct(idents, world, backend if use_dist else None)
     if rank == 0:
         log("timed region: {} steps in {:.2f} s".format(args.steps, dt))
 

@@ -134,9 +134,8 @@ def test_stopping_the_launcher_stops_its_ranks():
         pids, deadline = set(), time.time() + 240
         while len(pids) < 2 and time.time() < deadline:          # both ranks are up and asleep
             line = p.stderr.readline()
-            m = re.search(r"rank \d+ pid (\d+) sleeping", line)
-            if m:
-                pids.add(int(m.group(1)))
+            for pid in re.findall(r"rank \d+ pid (\d+) sleeping", line):      # two ranks may share one stderr line
+                pids.add(int(pid))
         assert len(pids) == 2, "the ranks did not start"
         family = psutil.Process(p.pid).children(recursive=True)
         assert pids <= {c.pid for c in family}
@@ -150,3 +149,52 @@ def test_stopping_the_launcher_stops_its_ranks():
         for pid in pids:
             if psutil.pid_exists(pid):
                 os.kill(pid, signal.SIGKILL)
+
+
+def test_visible_gpu_count_reads_the_kfd_topology_only(tmp_path, monkeypatch):
+    """The launcher's device count: KFD topology + render-node access, no GPU runtime.  A fake tree: two CPU nodes, one
+    GPU of this job, one GPU whose render node is missing (another tenant's), one node the cgroup hides (unreadable)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes, dev = tmp_path / "nodes", tmp_path / "dri"
+    dev.mkdir()
+    for i, (simd, minor) in enumerate([(0, 0), (0, 0), (1024, 128), (1024, 129), (1024, 130)]):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text("cpu_cores_count 0\nsimd_count {}\ndrm_render_minor {}\n".format(simd, minor))
+    (dev / "renderD128").write_text("")
+    (dev / "renderD130").write_text("")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(nodes), str(dev)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpu_count(str(nodes), str(dev)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count(str(nodes), str(dev)) == 2          # a list cannot add devices
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,-1,0")
+    assert bench.visible_gpu_count(str(nodes), str(dev)) == 1          # the runtimes stop at the first invalid entry
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert bench.visible_gpu_count(str(tmp_path / "absent"), str(dev)) == 0      # no KFD: no ROCm device
+    if os.geteuid() != 0:                                              # root reads through any mode
+        for i in range(5):
+            (nodes / str(i) / "properties").chmod(0)
+        assert bench.visible_gpu_count(str(nodes), str(dev)) is None   # nothing readable: unknown, never a refusal
+
+
+def test_the_launcher_never_asks_torch_for_the_device_count(monkeypatch):
+    """``launch_ranks`` must not reach ``torch.cuda.device_count`` (it falls back to hipGetDeviceCount when amdsmi does
+    not initialise -- then the parent has initialised HIP and may not start GPU children on these hosts)."""
+    import pytest
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def boom():
+        raise AssertionError("the launcher asked the GPU runtime")
+    monkeypatch.setattr(torch.cuda, "device_count", boom)
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
+    monkeypatch.delenv("VQA_DIST_BACKEND", raising=False)
+    args = type("A", (), dict(dry_run=False, gpus=2))()
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert "only 1 GPU(s) visible" in str(e.value)

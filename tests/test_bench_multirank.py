@@ -140,3 +140,117 @@ def test_plain_gpus_2_invocation_starts_two_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["collective"]["world"] == 2 and rec["collective"]["backend"] == "gloo"
     assert rec["value"] > 0 and rec["config"]["batch_per_gpu"] == 4
+
+
+def _rccl_refusal(out_path):
+    """``python bench.py --gpus 2`` with the DEFAULT backend (RCCL) on a one-GPU box, from a process that has not touched
+    the GPU: the launcher must refuse -- and must still be GPU-free when it does."""
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "VQA_DIST_BACKEND"):
+        os.environ.pop(k, None)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--model", "vlmo_tiny", "--batch", "2",
+                "--no-cpu-baseline", "--no-b256"]
+    import torch
+    import bench
+    report = {"count": bench.visible_gpu_count()}
+    try:
+        bench.main()
+        report["exit"] = "returned"
+    except SystemExit as e:
+        report["exit"] = str(e.code)
+    report["cuda_initialized"] = bool(torch.cuda.is_initialized())
+    fds = []
+    for f in os.listdir("/proc/self/fd"):
+        try:
+            fds.append(os.readlink("/proc/self/fd/" + f))
+        except OSError:
+            pass
+    report["gpu_fds"] = [f for f in fds if f.startswith("/dev/kfd") or f.startswith("/dev/dri")]
+    maps = open("/proc/self/maps").read()
+    report["runtime_mapped"] = [lib for lib in ("libamdhip64", "libhsa-runtime64") if lib in maps]
+    with open(out_path, "w") as fh:
+        json.dump(report, fh)
+
+
+def test_rccl_launcher_refuses_two_ranks_on_one_gpu_and_stays_gpu_free(tmp_path):
+    """The RCCL branch of the self-launcher, executed: default backend, ``--gpus 2``, one visible GPU -> "only 1 GPU(s)
+    visible", no rank started; afterwards the launcher process has no initialised CUDA context and no ``/dev/kfd`` /
+    ``/dev/dri`` descriptor (``libamdhip64`` is mapped by ``import torch`` itself; what matters is that nothing was
+    opened through it)."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    ctx = multiprocessing.get_context("forkserver")
+    out = str(tmp_path / "refusal.json")
+    p = ctx.Process(target=_rccl_refusal, args=(out,))
+    p.start()
+    p.join(timeout=240)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("the launcher did not return within 240 s")
+    assert p.exitcode == 0
+    rep = json.load(open(out))
+    assert rep["count"] == 1
+    assert "only 1 GPU(s) visible" in rep["exit"], rep
+    assert rep["cuda_initialized"] is False and rep["gpu_fds"] == [], rep
+
+
+def _single_process_bench(out_path, argv):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        os.environ.pop(k, None)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py"] + list(argv)
+    out = open(out_path, "w")
+    os.dup2(out.fileno(), 1)
+    os.dup2(out.fileno(), 2)
+    import bench
+    bench.main()
+    sys.stdout.flush()
+
+
+def _bench_line(tmp_path, argv, name):
+    ctx = multiprocessing.get_context("forkserver")
+    out = str(tmp_path / name)
+    p = ctx.Process(target=_single_process_bench, args=(out, argv))
+    p.start()
+    p.join(timeout=420)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("bench.py did not finish within 420 s")
+    text = open(out).read()
+    assert p.exitcode == 0, text[-3000:]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text[-3000:]
+    return json.loads(lines[0])
+
+
+def test_sweep_with_the_input_and_output_steps_in_the_timed_region(tmp_path):
+    """``--sweep N --from-uint8``: 8-bit host images -> device resize + normalise before, ``<qid>.pt`` after every batch,
+    both inside the timed region, their host-visible share reported."""
+    rec = _bench_line(tmp_path, ["--gpus", "1", "--sweep", "48", "--warmup", "1", "--model", "vlmo_tiny", "--batch", "16",
+                                 "--pgd-steps", "8", "--from-uint8"], "uint8.out")
+    io = rec["input_pipeline"]
+    assert io is not None and len(io["input_seconds"]) == 1 and io["input_seconds"][0] > 0.0
+    assert 0.0 < io["share_of_seconds_attack"] < 1.0 and io["writer_seconds"][0] >= 0.0
+    assert rec["scaling"] == "strong" and rec["value"] > 0 and rec["per_rank"]["samples"] == [48]
+
+
+def test_emulated_shards_line_is_labelled_as_a_prediction(tmp_path):
+    """``--sweep N --emulate-world 4`` on one GPU: the four rank::4 shards in sequence; the line says so
+    (``strong-emulated``, ``n_gpus`` 1), carries per-shard records and the max / mean prediction -- never an N-GPU claim."""
+    rec = _bench_line(tmp_path, ["--gpus", "1", "--sweep", "50", "--warmup", "1", "--model", "vlmo_tiny", "--batch", "8",
+                                 "--pgd-steps", "8", "--emulate-world", "4"], "emulated.out")
+    assert rec["scaling"] == "strong-emulated" and rec["n_gpus"] == 1 and rec["distinct_devices"] == 1
+    em = rec["emulated"]
+    assert em["world"] == 4 and rec["per_rank"]["samples"] == [13, 13, 12, 12] and rec["collective"] is None
+    secs = rec["per_rank"]["seconds_attack"]
+    assert abs(em["shard_seconds_max"] - max(secs)) < 2e-3 and 0.0 < em["predicted_strong_scaling_efficiency"] <= 1.0
+    assert abs(em["predicted_value_at_world"] - 50 / max(secs)) <= 0.01 * em["predicted_value_at_world"]
+    assert abs(rec["value"] - 50 / rec["seconds"]) <= 0.01 * rec["value"] and rec["seconds"] >= sum(secs) * 0.99
+    assert "NOT a multi-GPU measurement" in em["what"]
+    asr = rec["attack_success_rate"]
+    assert abs(asr * 50 - round(asr * 50)) < 1e-3
