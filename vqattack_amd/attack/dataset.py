@@ -210,9 +210,10 @@ class _Uint8Source:
         self._fetch.close()
 
 
-class SyntheticUint8Pairs(SyntheticPairs, _Uint8Source):
+class SyntheticUint8Pairs(_Uint8Source, SyntheticPairs):
     """``SyntheticPairs``' questions with seeded 8-bit (480, 640, 3) images (a camera frame's shape) that go through the
-    real input pipeline: host array -> pinned upload -> ``csrc/image.hip`` resize + normalise."""
+    real input pipeline: host array -> pinned upload -> ``csrc/image.hip`` resize + normalise (``_Uint8Source`` comes
+    first in the bases: its ``prefetch`` / ``images`` / ``close`` are the ones that run)."""
 
     def __init__(self, n_samples, text_len, image_size, flavor, seed=0, joint=True, max_words=12, dual_every=0,
                  source_hw=(480, 640), workers=4):
@@ -223,9 +224,6 @@ class SyntheticUint8Pairs(SyntheticPairs, _Uint8Source):
     def _load_one(self, index):
         h, w = self.source_hw
         return np.random.RandomState(1_000_003 * int(index) + 17).randint(0, 256, (h, w, 3), dtype=np.uint8)
-
-    def close(self):
-        _Uint8Source.close(self)
 
 
 class VqaFilePairs(_Uint8Source):

@@ -301,7 +301,7 @@ class BatchedVQAttack:
         perm = torch.tensor(order, device=dev)
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(b, device=dev)
-        images, text_ids, text_masks, attackable = images[perm], text_ids[perm], text_masks[perm], attackable[perm]
+        images, text_ids, text_masks, attackable = images[perm].contiguous(), text_ids[perm], text_masks[perm], attackable[perm]
         if init_eta is not None:
             init_eta = init_eta[perm]
         kinds = [kinds[s] for s in order]
@@ -344,7 +344,7 @@ class BatchedVQAttack:
         flag = ops.new_flag(dev)
         eta = init_eta
         if eta is None and c.random_start:
-            eta = torch.empty_like(images).uniform_(-c.eps, c.eps)
+            eta = torch.empty_like(images, memory_format=torch.contiguous_format).uniform_(-c.eps, c.eps)
         cur = ops.linf_init(images.contiguous(), eta, c.eps, c.clip_min, c.clip_max, flag=flag)
         losses = torch.zeros(max(total), dtype=torch.float32, device=dev)
         ws = ops.Workspace()

@@ -399,7 +399,7 @@ def _start_point(x, norm, eps, clip_min, clip_max, time, rand_minmax, init_eta, 
                 raise ValueError("init_eta shape {} != x shape {}".format(tuple(eta.shape), tuple(x.shape)))
         else:
             r = eps if rand_minmax is None else rand_minmax
-            eta = torch.empty_like(x).uniform_(-r, r)
+            eta = torch.empty_like(x, memory_format=torch.contiguous_format).uniform_(-r, r)
         if norm == 2:
             eta = ops.scale_per_sample(eta, ops.sumsq_per_sample(eta), None, eps, kind=0)
     bound = eps if norm == np.inf else float("inf")
