@@ -114,6 +114,9 @@ def main():
         for s in range(args.n):
             if args.time_budget and time.perf_counter() - t0 > args.time_budget:
                 log("time budget reached after {} samples".format(s))
+                if s == 0:
+                    raise SystemExit("--time-budget {} s was reached before a single sample had been attacked: nothing "
+                                     "to score, no fixture written".format(args.time_budget))
                 args.n = s
                 ids, masks, att, images, eta = ids[:s], masks[:s], att[:s], images[:s], eta[:s]
                 oracle_tasks, proposals, adv_ids = oracle_tasks[:s], proposals[:s], adv_ids[:s]
@@ -177,7 +180,11 @@ def main():
     clean, after, margins = table[pick]
     bits = [int(a != c) for a, c in zip(after, clean)]
     rec = dict(
-        note="generated by tests/golden/make_asr_fixture.py in the build container (CPU oracle); data only",
+        note="generated by tests/golden/make_asr_fixture.py in the build container (CPU oracle); data only.  The scored "
+             "prefix n_scored (and with it the outcome-dependent choice of n_answers) depends on the host's speed when "
+             "--time-budget cut the run: regenerate THIS file with  --n {} --seed {} --upto {}  (no --time-budget)".format(
+                 n_all, args.seed, args.n),
+        regenerate=dict(n=n_all, seed=args.seed, upto=args.n, sizes=[int(k) for k in sizes], budget=args.budget),
         flavor=flavor, size="base", n=n_all, n_scored=args.n, seed=args.seed, budget=args.budget, sim_threshold=0.3, sim_seed=5,
         white_seed=3, black_seed=4, shape=dict(words=list(shape["words"]), max_att=shape["max_att"],
                                                text_len=shape["text_len"]),

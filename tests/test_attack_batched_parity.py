@@ -477,7 +477,7 @@ def test_vlmo_mixed_loss_on_a_ragged_batch_matches_per_sample_oracle():
         with torch.enable_grad():
             want, ls_s = o.fast_gradient_method(ref.pgd_mlm_attack, start[s:s + 1], 0.01, np.inf, images[s:s + 1],
                                                 clip_min=-1, clip_max=1, y=ys, ls=2, flavor="vlmo")
-        want_loss += float(ls_s)
+        want_loss += float(ls_s.detach()) if torch.is_tensor(ls_s) else float(ls_s)
         same = (adv[s].cpu() == want[0].detach()).float().mean().item()
         assert same >= 0.99, (s, same)
     assert abs(float(loss) - want_loss) <= 2e-4 * abs(want_loss)

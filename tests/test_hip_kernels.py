@@ -647,3 +647,27 @@ def test_greedy_accept_on_device_equals_host_loop():
         assert np.array_equal(got.cpu().numpy(), want_ids), thr
         assert text_update.substitution_lists(prev, new_id, rank) == want_ops
     assert any(len(o) for o in want_ops)
+
+
+def test_a_bad_mlm_label_fails_the_step_also_without_sanity_checks():
+    """``F.cross_entropy`` with a target outside the vocabulary never returns in the reference, whatever ``sanity_checks``
+    says (fast_gradient_method.py:133-139: IndexError on the host, a device assert on a GPU); here the CE kernel sets
+    VQA_FLAG_BAD_LABEL and the norm-1 / norm-2 operators -- which read the flag word anyway for optimize_linear's own
+    assert -- raise on it instead of stepping along a NaN gradient."""
+    from vqattack_amd import attacks
+    g = torch.Generator(device=DEV).manual_seed(0)
+    w = torch.randn(3 * 8 * 8, 30522, device=DEV, generator=g) * 0.01
+    x = torch.empty(2, 3, 8, 8, device=DEV).uniform_(-0.5, 0.5, generator=g)
+
+    def model_fn(img):
+        return [(img.reshape(2, 1, -1) @ w)]                       # logits (B, L = 1, V)
+
+    good = torch.tensor([[5], [77]], device=DEV)
+    bad = torch.tensor([[5], [30522]], device=DEV)
+    for norm in (1, 2):
+        adv, loss = attacks.fast_gradient_method(model_fn, x, 0.1, norm, x, clip_min=-1, clip_max=1, y=[good], ls=0,
+                                                 sanity_checks=False, flavor="albef")
+        assert torch.isfinite(adv).all()
+        with pytest.raises(AssertionError, match="MLM label"):
+            attacks.fast_gradient_method(model_fn, x, 0.1, norm, x, clip_min=-1, clip_max=1, y=[bad], ls=0,
+                                         sanity_checks=False, flavor="albef")

@@ -7,11 +7,15 @@
 #   3. the tie probe (tools/asr_tie_probe.py) for every sample whose success bit differs, while the oracle's adversarial
 #      images still exist in the box's /tmp (they never travel: 1.8 MB each).
 # usage: tools/asr_box_round.sh <out_dir under gpurun_out> "<vlmo seeds>" "<albef seeds>" [attack seconds]
-# The fixtures land in <out_dir>; copy them to tests/golden/ afterwards.  Test infrastructure (runs oracle/).
+# The fixtures land in <out_dir> and are copied into tests/golden/ of the BOX's snapshot so that the product run can read
+# them (provisional: that tree does not travel back); copy them from <out_dir> to tests/golden/ afterwards -- only when this
+# script exits 0: its exit status is the product-side pytest's.  Test infrastructure (runs oracle/).
 set -o pipefail
 out=$1; vs=($2); as=($3); budget=${4:-560}
 mkdir -p "$out" /tmp/asr_cache_box
-n=$(( ${#vs[@]} + ${#as[@]} )); threads=$(( 16 / n )); [ $threads -lt 1 ] && threads=1
+n=$(( ${#vs[@]} + ${#as[@]} ))
+[ $n -gt 0 ] || { echo "usage: $0 <out_dir> \"<vlmo seeds>\" \"<albef seeds>\" [seconds]: no seed given"; exit 2; }
+threads=$(( 16 / n )); [ $threads -lt 1 ] && threads=1
 pids=(); keys=()
 for s in "${vs[@]}"; do
   python tests/golden/make_asr_fixture.py --flavor vlmo --n 120 --seed $s --threads $threads --cache /tmp/asr_cache_box \
@@ -32,7 +36,8 @@ for k in "${keys[@]}"; do cp "$out/asr_base_$k.json" tests/golden/; sel="$sel${s
 tag=$(echo "${keys[@]}" | tr ' ' '_')
 VQA_ASR_FULL=1 VQA_ASR_SETS_LOG="$out/sets_$tag.jsonl" python -m pytest tests/test_success_bits_base.py -m gpu -q -s \
     -k "$sel" > "$out/pytest_$tag.log" 2>&1
-echo "pytest rc $?"; grep -E "base: n =|passed|failed" "$out/pytest_$tag.log"
+rc=$?
+echo "pytest rc $rc"; grep -E "base: n =|passed|failed" "$out/pytest_$tag.log"
 python - "$out" "$out/sets_$tag.jsonl" <<'PY'
 import json, os, subprocess, sys
 out, log = sys.argv[1:3]
@@ -47,3 +52,4 @@ for line in open(log) if os.path.exists(log) else []:
     with open(os.path.join(out, "asr_tie_probes.jsonl"), "a") as f:
         subprocess.run(cmd, stdout=f, stderr=open(os.path.join(out, "tie_probe.err"), "a"))
 PY
+exit $rc

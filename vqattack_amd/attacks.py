@@ -319,18 +319,22 @@ def _fgm_then_project(x, grad, x0, eps_iter, eps, norm, clip_min, clip_max, out,
 
 
 def _check_flag(flag, norm, sanity_checks):
-    """The one host read of an operator call's flag word.  The degenerate-gradient bit is the reference's unconditional
-    ``assert`` inside ``optimize_linear`` (norm 1 / 2 only, utils.py:101-104,110-116); the range and label bits are
-    ``sanity_checks`` material and are not looked at without it (the reference evaluates its range asserts only under
-    ``sanity_checks``: fast_gradient_method.py:162-163).  Returns True when no sanity bit counts against the call."""
+    """The one host read of an operator call's flag word.  Two bits are the reference's UNCONDITIONAL failures and are
+    raised whenever the word is read at all (norm 1 / 2, or ``sanity_checks``): the degenerate-gradient bit
+    (``optimize_linear``'s own ``assert``, utils.py:101-104,110-116) and the bad-MLM-label bit (``F.cross_entropy`` with
+    a target outside the vocabulary never returns in the reference -- IndexError on the host, a device assert on a GPU,
+    fast_gradient_method.py:133-139).  Only the range bit is ``sanity_checks`` material (the reference evaluates its
+    range asserts under ``sanity_checks`` only: fast_gradient_method.py:162-163).  The L-inf path without
+    ``sanity_checks`` never reads the word (no host sync per call); there a bad label surfaces as the NaN loss the
+    kernel writes.  Returns True when no sanity bit counts against the call."""
     if flag is None or not (sanity_checks or norm != np.inf):
         return True
     bits = int(flag.item())
     assert not bits & VQA_FLAG_DEGENERATE, \
         "optimize_linear: the optimal perturbation does not have unit norm (all-zero or non-finite gradient)"
+    assert not bits & VQA_FLAG_BAD_LABEL, "an MLM label is outside [0, vocabulary) and is not ignore_index"
     if not sanity_checks:
         return True
-    assert not bits & VQA_FLAG_BAD_LABEL, "an MLM label is outside [0, vocabulary) and is not ignore_index"
     return (bits & VQA_FLAG_RANGE) == 0
 
 

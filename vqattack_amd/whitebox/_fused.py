@@ -43,9 +43,12 @@ def supported(dim, heads):
 
 def weights_key(module):
     """Fingerprint of the frozen weights a spec was built from: storage address and in-place version counter of every
-    parameter.  ``load_state_dict`` (copy or ``assign=True``), ``.to()`` and any in-place update change it, so a cached
-    spec -- which may hold COPIES (ALBEF's packed q/k/v, contiguous copies of strided parameters) -- is rebuilt instead
-    of silently running on stale weights.  ~0.1 us per parameter, once per encoder pass."""
+    parameter.  Detected: ``load_state_dict`` (copying or ``assign=True``), ``.to()``, ``p.copy_()`` / any in-place op ON
+    THE PARAMETER.  NOT detected: writes through ``p.data`` (``p.data.copy_(w)``, ``p.data.add_(1)``) -- ``.data`` is a
+    detached alias with its own version counter, so the key stays equal and a cached spec that holds COPIES (ALBEF's
+    packed q / k / v, contiguous copies of strided parameters) would keep the old values.  Code that updates weights
+    that way calls ``invalidate_fused()`` on the model (``FrozenVlmo`` / ``FrozenAlbef``); the reference-checkpoint
+    loaders do.  ~0.1 us per parameter, once per encoder pass."""
     return tuple((p.data_ptr(), p._version) for p in module.parameters())
 
 

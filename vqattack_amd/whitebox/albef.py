@@ -212,6 +212,11 @@ class FrozenAlbef(nn.Module):
                     p.copy_(w + drift * rms * torch.empty(w.shape).normal_(generator=g))
         return black
 
+    def invalidate_fused(self):
+        """Drop the cached fused-encoder spec: the next pass rebuilds it from the current weights.  Needed only after
+        weight updates ``_fused.weights_key`` cannot see (writes through ``p.data``)."""
+        self._fused_spec = None
+
     # ---- reference checkpoints ------------------------------------------------------------------------------
     def load_reference_state_dict(self, state_dict, strict=True):
         """Fill this model from a state dict of the reference's ``ALBEF_pre`` (white box, adv_attack.py:83-92) or

@@ -268,7 +268,7 @@ def load_vlmo(model, state_dict, strict=True, max_text_len_of_initckpt=None):
                                                                                         tuple(model.rel_pos_bias.shape)))
     with torch.no_grad():
         model.rel_pos_bias.copy_(bias)
-    model._fused_spec = None
+    model.invalidate_fused()
     unexpected = sorted(k for k in sd if k not in used and not k.endswith("relative_position_index"))
     hard = [m for m in missing if m != "vqa_classifier"]
     if strict and hard:
@@ -397,7 +397,7 @@ def load_albef(model, state_dict, strict=True):
             used.update((dc + "bias", dc + "decoder.weight", dc + "decoder.bias"))
         else:
             missing.append("text_decoder")
-    model._fused_spec = None
+    model.invalidate_fused()
     unexpected = sorted(k for k in sd if k not in used)
     hard = [m for m in missing if not (m == "text_encoder.cls" and model.has_vqa)]
     if strict and hard:

@@ -238,6 +238,11 @@ class FrozenVlmo(nn.Module):
             black.rel_pos_bias.copy_(white.rel_pos_bias.detach().cpu())
         return black
 
+    def invalidate_fused(self):
+        """Drop the cached fused-encoder spec: the next pass rebuilds it from the current weights.  Needed only after
+        weight updates ``_fused.weights_key`` cannot see (writes through ``p.data``)."""
+        self._fused_spec = None
+
     # ---- reference checkpoints ------------------------------------------------------------------------------
     def set_mlm_decoder(self, weight):
         """Untie the MLM decoder from the word embeddings (``weight`` (V, D)); None ties it again."""
