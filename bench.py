@@ -392,31 +392,39 @@ def build_models(args, cfg, device):
 
 
 # HBM traffic per launch is NOT measured by this script (PMC counters need their own rocprofv3 passes): the tracked JSON
-# below holds, per phase of tools/pmc_step.py, the launch SHAPE it ran and FETCH_SIZE x 2 (gfx950 correction) +
-# WRITE_SIZE per launch and kernel (tools/pmc_run.sh on the shipped build).  A figure is copied into the line -- as
-# `traffic` with `traffic_kind: "recorded"` -- only when the run's launch has exactly the recorded shape.
-PMC_TRAFFIC = "profiles/r05/pmc_traffic.json"
+# below holds, per phase of tools/pmc_step.py, the launch SHAPE it ran, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per
+# launch and kernel, and the sha256 of the kernel's source (tools/pmc_run.sh on the shipped build).  A figure is copied
+# into the line -- as `traffic` with `traffic_kind: "recorded"` -- only when the run's launch has exactly the recorded
+# shape AND the kernel's source in this tree still has the recorded digest; after a kernel edit without a new PMC pass
+# the field is null and says why.
+PMC_TRAFFIC = next((p for p in ("profiles/r06/pmc_traffic.json", "profiles/r05/pmc_traffic.json")
+                    if os.path.exists(os.path.join(ROOT, p))), "profiles/r06/pmc_traffic.json")
 
 
 def recorded_traffic(kernel, shape):
-    """(HBM bytes per launch, phase) of the record whose kernel name contains `kernel` and whose shape dict equals
-    `shape`; (None, None) when the tracked file has no such record."""
+    """(HBM bytes per launch, phase, why-not) of the record whose kernel name contains `kernel`, whose shape dict equals
+    `shape` and whose source digest is this tree's; (None, None, reason) otherwise."""
+    from vqattack_amd.build import kernel_source_digest
     try:
         records = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
     except (OSError, ValueError):
-        return None, None
+        return None, None, "no record file"
+    why = "no record of this kernel and launch shape"
     for rec in records:
         if kernel in rec.get("kernel", "") and rec.get("shape") == shape:
-            return int(rec["traffic_bytes"]), rec.get("phase")
-    return None, None
+            if rec.get("source_sha256") is None or rec["source_sha256"] != kernel_source_digest(rec["kernel"]):
+                why = "stale: the kernel's source changed since the PMC pass (phase {})".format(rec.get("phase"))
+                continue
+            return int(rec["traffic_bytes"]), rec.get("phase"), None
+    return None, None, why
 
 
 def traffic_fields(kernel, shape):
-    t, phase = recorded_traffic(kernel, shape) if shape else (None, None)
+    t, phase, why = recorded_traffic(kernel, shape) if shape else (None, None, "no shape")
     if t is None:
-        return dict(traffic=None, traffic_source=PMC_TRAFFIC, traffic_shape=shape)
+        return dict(traffic=None, traffic_source=PMC_TRAFFIC, traffic_shape=shape, traffic_missing=why)
     return dict(traffic=t, traffic_kind="recorded", traffic_shape=shape,
-                traffic_source="{} (phase {}: the same launch shape)".format(PMC_TRAFFIC, phase))
+                traffic_source="{} (phase {}: the same launch shape, the same kernel source)".format(PMC_TRAFFIC, phase))
 
 
 class KernelTimer:

@@ -198,3 +198,29 @@ def test_the_launcher_never_asks_torch_for_the_device_count(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.launch_ranks(args)
     assert "only 1 GPU(s) visible" in str(e.value)
+
+
+def test_recorded_traffic_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
+    """``roofline.traffic`` is a COPIED counter reading: it is handed out only for the recorded launch shape and only while
+    the kernel's source (its .hip file + common.hpp + the C-ABI header + flags) still has the digest of the PMC pass."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from vqattack_amd.build import kernel_source_digest
+    name = "vqa::stream4_kernel<vqa::StepOp, 4, 5>"
+    shape = {"elements": 28311552, "op": "linf_step"}
+    good = kernel_source_digest(name)
+    assert good and good != kernel_source_digest("vqa::neg_cos_rows_kernel<3, true, true, 4>") and \
+        kernel_source_digest("some_other_kernel") is None
+    rec = dict(phase="step64", kernel=name, shape=shape, traffic_bytes=453058560, source_sha256=good)
+    path = tmp_path / "pmc_traffic.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC", "pmc_traffic.json")
+    path.write_text(json.dumps([rec]))
+    assert bench.recorded_traffic("stream4_kernel<vqa::StepOp", shape) == (453058560, "step64", None)
+    assert bench.traffic_fields("stream4_kernel<vqa::StepOp", dict(shape, elements=1))["traffic"] is None
+    path.write_text(json.dumps([dict(rec, source_sha256="0" * 64)]))
+    t, _, why = bench.recorded_traffic("stream4_kernel<vqa::StepOp", shape)
+    assert t is None and "stale" in why
+    path.write_text(json.dumps([{k: v for k, v in rec.items() if k != "source_sha256"}]))     # a pre-digest record
+    fields = bench.traffic_fields("stream4_kernel<vqa::StepOp", shape)
+    assert fields["traffic"] is None and "stale" in fields["traffic_missing"]

@@ -5,8 +5,9 @@ i.e. exactly half of a wide coalesced stream (MI355X_MICROARCH.md, HBM section),
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv>
                       [--json records.json --phase <name> --shape '<json>']
 With --json every kernel's per-launch figures are appended to a JSON list of records
-{phase, kernel, grid, shape, fetch_bytes, write_bytes, traffic_bytes, launches, dur_us}: bench.py matches a run's launch
-against `kernel` and `shape` before it copies `traffic_bytes` into its line.
+{phase, kernel, grid, shape, fetch_bytes, write_bytes, traffic_bytes, launches, dur_us, source_sha256}: bench.py matches
+a run's launch against `kernel` and `shape` -- and the sha256 of the kernel's source file + common.hpp + the C-ABI header
+(vqattack_amd.build.kernel_source_digest) against the tree it runs from -- before it copies `traffic_bytes` into its line.
 """
 import csv
 import json
@@ -15,6 +16,8 @@ import sys
 from collections import defaultdict
 
 csv.field_size_limit(1 << 30)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqattack_amd.build import kernel_source_digest  # noqa: E402
 
 
 def load(path, counter):
@@ -47,7 +50,7 @@ for key in sorted(fetch):
                         shape=json.loads(opts["--shape"]) if opts.get("--shape") else None,
                         fetch_bytes=int(round(fetch_b)), write_bytes=int(round(write_b)),
                         traffic_bytes=int(round(fetch_b + write_b)), launches=len(fetch[key]),
-                        dur_us=round(dur / 1e3, 1)))
+                        dur_us=round(dur / 1e3, 1), source_sha256=kernel_source_digest(key[0])))
 if opts.get("--json"):
     path = opts["--json"]
     old = json.load(open(path)) if os.path.exists(path) else []

@@ -20,6 +20,30 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wall", "-Wno-unused-function"]
 
 
+# which source file a kernel of the library lives in (by a substring of its demangled name) -- for records that must be
+# tied to the code that produced them (profiles/*/pmc_traffic.json, bench.py's `traffic` field)
+KERNEL_SOURCES = (("stream4_kernel", "linf.hip"), ("neg_cos_rows", "loss.hip"), ("ce_rows", "ce.hip"), ("ce_count", "ce.hip"),
+                  ("attn_", "attn.hip"), ("sumsq", "lnorm.hip"), ("absmax", "lnorm.hip"), ("per_sample", "lnorm.hip"),
+                  ("sum_stage2", "lnorm.hip"), ("ln_fwd", "block.hip"), ("ln_bwd", "block.hip"), ("gelu", "block.hip"),
+                  ("resize", "image.hip"), ("gather_rows", "text.hip"), ("cand_dir_sim", "text.hip"),
+                  ("embed_tokens", "text.hip"), ("greedy_accept", "text.hip"))
+
+
+def kernel_source_digest(kernel_name):
+    """sha256 over the source file a kernel is compiled from + ``common.hpp`` + the C-ABI header + the compiler flags:
+    changes whenever that kernel's code object can have changed.  None for a kernel this table does not know."""
+    import hashlib
+    src = next((f for key, f in KERNEL_SOURCES if key in kernel_name), None)
+    if src is None:
+        return None
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in (os.path.join(SRC_DIR, src), os.path.join(SRC_DIR, "common.hpp"),
+                 os.path.join(HERE, "..", "include", "vqattack_hip.h")):
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -56,4 +80,7 @@ def build(force=False, verbose=False, tuning=False):
 
 
 if __name__ == "__main__":
+    if "--digest" in sys.argv:                       # python -m vqattack_amd.build --digest <kernel name>
+        print(kernel_source_digest(sys.argv[sys.argv.index("--digest") + 1]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
