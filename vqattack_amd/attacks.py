@@ -330,9 +330,10 @@ def _check_flag(flag, norm, sanity_checks):
     if flag is None or not (sanity_checks or norm != np.inf):
         return True
     bits = int(flag.item())
+    # the label first: its NaN loss makes the gradient non-finite, which then trips the degenerate bit as well
+    assert not bits & VQA_FLAG_BAD_LABEL, "an MLM label is outside [0, vocabulary) and is not ignore_index"
     assert not bits & VQA_FLAG_DEGENERATE, \
         "optimize_linear: the optimal perturbation does not have unit norm (all-zero or non-finite gradient)"
-    assert not bits & VQA_FLAG_BAD_LABEL, "an MLM label is outside [0, vocabulary) and is not ignore_index"
     if not sanity_checks:
         return True
     return (bits & VQA_FLAG_RANGE) == 0

@@ -27,12 +27,21 @@ class VlmoReferenceClosures:
 
     def __init__(self, model, batch):
         self.model, self.batch = model, batch
+        self._real = None
+
+    def _real_text(self, text_masks):
+        """``torch.where(text_masks[0] == 1)`` (vlmo_module.py:1441) -- a device->host read (the index list's length).
+        The reference pays it in every forward; here it is taken once per text batch (keyed on the mask tensor and its
+        in-place version), which also makes the closure capturable into a hipGraph (``graph=True``)."""
+        key = (text_masks.data_ptr(), text_masks._version, tuple(text_masks.shape))
+        if self._real is None or self._real[0] != key:
+            self._real = (key, torch.where(text_masks[0] == 1)[0])
+        return self._real[1]
 
     def _packed(self, feats, states, text_masks):
         target = torch.stack(feats, axis=1)                                  # (1, depth + 1, L + N, D)
         image_part = target[0, :, self.model.cfg.max_text_len:]              # the reference's literal 40
-        real_text = torch.where(text_masks[0] == 1)
-        per_token = torch.cat([target[0, :, real_text[0]], image_part], axis=1)
+        per_token = torch.cat([target[0, :, self._real_text(text_masks)], image_part], axis=1)
         return self.model.pooled(states), target[0, :, 0, :], per_token
 
     def pgd_attack(self, x):
