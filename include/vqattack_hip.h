@@ -285,11 +285,18 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
  * and query -- the padded text tokens of a question shorter than the batch's text length (key padding of the reference's
  * attention mask).  It lets a ragged batch share ONE (1, H, S, S) relative-position slab (batch stride 0) instead of a
  * per-sample (B, H, S, S) bias.  The stored scores carry the -inf, so the scores-based backward needs nothing else; the
- * score-recomputing forms of vqa_attn_bwd do not know the hole: callers that use them pass the padding inside `bias`. */
+ * score-recomputing forms of vqa_attn_bwd do not know the hole: callers that use them pass the padding inside `bias`.
+ * nsplit / split_ws (ABI v4): nsplit == 1 (split_ws ignored) is the form above: one workgroup per (batch, head, 128
+ * queries) walks all key tiles.  nsplit > 1 is for SMALL batches -- the reference's own batch 1 gives 12 heads x 5
+ * blocks = 60 workgroups for 256 CUs, each a serial chain over ~19 tiles: the key loop is cut into nsplit parts
+ * (nsplit <= ceil(Sk / 32)), every part is its own workgroup writing partial accumulators + (running maximum, row sum)
+ * into split_ws (vqa_attn_split_ws_floats(B, H, Sq, Sk, nsplit) floats, 16-byte aligned), and a second kernel combines
+ * the parts in index order (flash-decoding reduction; deterministic, results equal the unsplit form to fp32 rounding). */
 int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
                  int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
-                 const int* key_hole, vqa_stream_t stream);
+                 const int* key_hole, int nsplit, float* split_ws, vqa_stream_t stream);
 long vqa_attn_scores_floats(int B, int H, int Sq, int Sk);
+long vqa_attn_split_ws_floats(int B, int H, int Sq, int Sk, int nsplit);
 
 /* Gradients of the above w.r.t. q, k, v given go = d loss / d o (the bias is frozen: no gradient).  Deterministic (no
  * float atomics: bitwise reproducible), two forms:
@@ -301,11 +308,14 @@ long vqa_attn_scores_floats(int B, int H, int Sq, int Sk);
  *   ds_ws == NULL: 7 products, no workspace: one kernel owns query blocks (dq; it also writes delta), one owns key
  *     blocks (dk, dv); both recompute the probabilities from lse.
  * grad_strides[12] = {go_sb, go_ss, go_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh} (elements;
- * dq / dk / dv may be the three slices of one packed (B, S, 3, H, 64) gradient buffer). */
+ * dq / dk / dv may be the three slices of one packed (B, S, 3, H, 64) gradient buffer).
+ * nsplit / split_ws (ABI v4; needs ds_ws and scores): as in vqa_attn_fwd -- the key-block kernel's loop over query
+ * tiles and the dq kernel's loop over key tiles are cut into nsplit parts (nsplit <= min(ceil(Sq / 32), ceil(Sk / 32)))
+ * whose partial dk / dv / dq are summed in part order by a small kernel (the same split_ws serves both, in turn). */
 int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
                  const float* lse, const float* scores, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B,
                  int H, int Sq, int Sk, const long* strides, const long* bias_strides, const long* grad_strides,
-                 float scale, vqa_stream_t stream);
+                 float scale, int nsplit, float* split_ws, vqa_stream_t stream);
 long vqa_attn_bwd_ws_floats(int B, int H, int Sq, int Sk);
 
 /* ---------------------------------------------------------------- input pipeline

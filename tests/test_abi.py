@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_no_compute_entry_points():
     """Only the argument-free queries are callable without a GPU."""
     lib = _hip.lib()
-    assert lib.vqa_abi_version() == 3
+    assert lib.vqa_abi_version() == 4
     assert lib.vqa_neg_cos_partials() > 0
     assert lib.vqa_reduce_ws_bytes(4, 3 * 384 * 384) > 0
     assert lib.vqa_error_string(-1).decode().startswith("a required pointer")

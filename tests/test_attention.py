@@ -206,3 +206,58 @@ def test_cross_attention_25_text_queries_over_901_image_keys(bias_kind, form, mo
     for name, g_, t in zip("qkv", got, (q, k, v)):
         scale = float(t.grad.abs().max()) + 1e-6
         assert float((g_ - t.grad).abs().max()) <= 1e-4 * scale, (name, float((g_ - t.grad).abs().max()), scale)
+
+
+@pytest.mark.parametrize("b,h,s,n", [(1, 12, 591, 8), (1, 12, 591, 3), (2, 3, 200, 2), (1, 2, 915, 5), (1, 1, 64, 2)])
+def test_loop_split_equals_the_unsplit_kernels(b, h, s, n, monkeypatch):
+    """Small batches cut the kernels' tile loops into ``n`` parts (workgroups per (batch, head, block) instead of one) and
+    combine the partial results in part order: forward (flash-decoding reduction of partial maxima / sums / accumulators)
+    and the scores-based backward (partial dk / dv / dq summed) against the unsplit kernels on the same operands -- with
+    a shared bias slab and a key hole that crosses a part boundary -- and bitwise reproducible run to run."""
+    from vqattack_amd import attention
+    g = torch.Generator(device=DEV).manual_seed(11)
+    qkv = torch.randn(b, s, 3, h, 64, device=DEV, generator=g)
+    pad = (s + 31) // 32 * 32
+    slab = (torch.randn(1, h, s, pad, device=DEV, generator=g) * 0.4)[..., :s].expand(b, -1, -1, -1)
+    hole = torch.tensor([[min(30 + 7 * i, s - 2), min(70 + 9 * i, s - 1)] for i in range(b)], dtype=torch.int32, device=DEV)
+    go = torch.randn(b, s, h, 64, device=DEV, generator=g)
+
+    def run(parts):
+        monkeypatch.setenv("VQA_ATTN_SPLIT", str(parts))
+        assert attention.loop_split(b, h, s, s, DEV) == parts
+        x = qkv.clone().requires_grad_(True)
+        o = attention.self_attention_packed(x, attention.KeyHoleBias(slab, hole))
+        o.backward(go)
+        return o.detach(), x.grad
+
+    o1, g1 = run(1)
+    on, gn = run(n)
+    on2, gn2 = run(n)
+    assert torch.equal(on, on2) and torch.equal(gn, gn2)                       # fixed part order: no atomics
+    assert torch.allclose(on, o1, atol=2e-6, rtol=1e-5), float((on - o1).abs().max())
+    assert float((gn - g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+    ref = _sdpa(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attention.KeyHoleBias(slab, hole).dense())
+    assert torch.allclose(on, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_loop_split_heuristic_and_abi_validation(monkeypatch):
+    from vqattack_amd import _hip, attention
+    monkeypatch.delenv("VQA_ATTN_SPLIT", raising=False)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert attention.loop_split(64, 12, 591, 591, DEV) == 1                  # the benchmark's shape fills the chip
+    n1 = attention.loop_split(1, 12, 591, 591, DEV)                          # the reference's own batch 1 does not
+    assert 2 <= n1 <= 8 and 12 * 5 * n1 <= 2 * cus + 12 * 5
+    assert attention.loop_split(1, 1, 20, 20, DEV) == 1                      # one tile: nothing to cut
+    lib = _hip.lib()
+    assert lib.vqa_attn_split_ws_floats(1, 12, 591, 591, 1) == 0
+    assert lib.vqa_attn_split_ws_floats(1, 12, 591, 591, 4) == max(12 * 591 * 4 * 66, 2 * 12 * 591 * 4 * 64)
+    q = torch.randn(1, 40, 2, 64, device=DEV)
+    o, lse = torch.empty_like(q), torch.empty(1, 2, 40, device=DEV)
+    strides = attention._longs([q.stride(0), q.stride(1), q.stride(2)] * 4)
+    ws = torch.empty(lib.vqa_attn_split_ws_floats(1, 2, 40, 40, 2), device=DEV)
+    args = (_hip.ptr(q), _hip.ptr(q), _hip.ptr(q), None, _hip.ptr(o), _hip.ptr(lse), None, 1, 2, 40, 40, strides, None, 0.125, None)
+    assert lib.vqa_attn_fwd(*args, 2, _hip.ptr(ws), None) == 0
+    assert lib.vqa_attn_fwd(*args, 3, _hip.ptr(ws), None) == -2                       # VQA_ERR_SHAPE: 2 key tiles: at most 2 parts
+    assert lib.vqa_attn_fwd(*args, 2, None, None) == -1                              # VQA_ERR_NULL
+    assert lib.vqa_attn_fwd(*args, 0, None, None) == -2
+    torch.cuda.synchronize()

@@ -20,7 +20,7 @@ VQA_CHECK_RANGE = 2
 VQA_FLAG_RANGE = 1        # bits of a flag word
 VQA_FLAG_BAD_LABEL = 2
 VQA_FLAG_DEGENERATE = 4   # optimize_linear's self-check would fail (all-zero / NaN L1 gradient, non-finite L2 norm)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_float_p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -60,9 +60,10 @@ SIGNATURES = {
     "vqa_cand_dir_sim": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vqa_embed_tokens": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
     "vqa_greedy_accept": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
-    "vqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _p]),
+    "vqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _i, _p, _p]),
+    "vqa_attn_split_ws_floats": (_l, [_i, _i, _i, _i, _i]),
     "vqa_attn_scores_floats": (_l, [_i, _i, _i, _i]),
-    "vqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p]),
+    "vqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p]),
     "vqa_attn_bwd_ws_floats": (_l, [_i, _i, _i, _i]),
     "vqa_ln_fwd": (_i, [_p] * 13 + [_l, _i, _l, _l, _f, _p]),
     "vqa_ln_bwd": (_i, [_p] * 13 + [_l, _i, _l, _l, _p]),

@@ -108,11 +108,42 @@ def _split_hole(bias):
     return bias, None
 
 
+_CUS = {}
+
+
+def loop_split(b, h, sq, sk, device):
+    """Parts the kernels' tile loops are cut into for this shape (1 = not at all).  A launch has
+    ``b * h * ceil(s / 128)`` workgroups, each a serial chain over ``ceil(s / 32)`` tiles: with fewer workgroups than the
+    chip can hold (2 per CU) -- the reference's own batch 1: 60 on 256 CUs -- the loop is cut so that about that many
+    run, at most 8 parts and never fewer than 2 tiles per part.  ``VQA_ATTN_SPLIT=n`` pins it (experiments)."""
+    import os
+    pinned = os.environ.get("VQA_ATTN_SPLIT")
+    tiles = (min(sq, sk) + 31) // 32
+    if pinned:
+        return max(1, min(int(pinned), tiles))
+    dev = torch.device(device).index or 0
+    if dev not in _CUS:
+        _CUS[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    wgs = b * h * ((max(sq, sk) + 127) // 128)
+    want = 2 * _CUS[dev]
+    if wgs * 2 > want:
+        return 1
+    return max(1, min(8, tiles // 2, -(-want // wgs)))
+
+
+def _split_ws(b, h, sq, sk, nsplit, device):
+    if nsplit <= 1:
+        return None
+    return torch.empty(int(lib().vqa_attn_split_ws_floats(b, h, sq, sk, nsplit)), dtype=torch.float32, device=device)
+
+
 def _forward(q, k, v, bias, bstr, scale, save_scores=False, key_hole=None):
     """Returns (o, lse, scores); ``scores`` is None unless ``save_scores`` and the buffer fits SCORES_LIMIT.
     ``key_hole``: int32 (B, 2) device tensor, see ``KeyHoleBias``."""
     b, sq, h, _ = q.shape
     sk = k.shape[1]
+    nsplit = loop_split(b, h, sq, sk, q.device)
+    sws = _split_ws(b, h, sq, sk, nsplit, q.device)
     o = torch.empty((b, sq, h, HEAD_DIM), dtype=torch.float32, device=q.device)
     lse = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
     scores = None
@@ -130,7 +161,8 @@ def _forward(q, k, v, bias, bstr, scale, save_scores=False, key_hole=None):
     with torch.cuda.device(q.device):
         check(lib().vqa_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(lse), ptr(scores), b, h, sq, sk, strides,
                                  _longs(bstr) if bstr else None, scale,
-                                 None if key_hole is None else ctypes.c_void_p(key_hole.data_ptr()), stream_for(q)),
+                                 None if key_hole is None else ctypes.c_void_p(key_hole.data_ptr()), nsplit, ptr(sws),
+                                 stream_for(q)),
               "vqa_attn_fwd")
     return o, lse, scores
 
@@ -189,10 +221,13 @@ def _backward(q, k, v, bias, bstr, o, lse, go, dq, dk, dv, scale, workspace=True
                       v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2)])
     gstr = _longs([go.stride(0), go.stride(1), go.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
                    dk.stride(0), dk.stride(1), dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2)])
+    nsplit = loop_split(b, h, sq, sk, q.device) if (ws is not None and scores is not None) else 1
+    sws = _split_ws(b, h, sq, sk, nsplit, q.device)
     with torch.cuda.device(q.device):
         check(lib().vqa_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(bias), ptr(o), ptr(go), ptr(lse),
                                  ptr(scores if ws is not None else None), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(ws),
-                                 b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr, scale, stream_for(q)),
+                                 b, h, sq, sk, strides, _longs(bstr) if bstr else None, gstr, scale, nsplit, ptr(sws),
+                                 stream_for(q)),
               "vqa_attn_bwd")
 
 

@@ -89,6 +89,36 @@ __device__ __forceinline__ BlockCoord block_coord(int n_blk, int B, int H) {
   return BlockCoord{p % B, p / B, blk};
 }
 
+// ------------------------------------------------------------------------------------------------ loop split
+// Small batches (the reference's own batch 1: 12 heads x 5 blocks = 60 workgroups on 256 CUs) leave the chip idle and a
+// workgroup's time is its SERIAL chain over ~19 tiles.  SPLIT kernels cut that loop into `n` parts: workgroup (block,
+// part) runs tiles [part * T / n, (part + 1) * T / n) and writes a PARTIAL result into `ws`; a small combine kernel
+// reduces the parts in a fixed order (bitwise reproducible).  Forward partials: the unnormalised O^T accumulators plus
+// (running maximum * log2 e, row sum) per query -- the flash-decoding reduction; backward partials: plain sums.
+// Layouts (rows = B * H * S of the reduced quantity):  forward  ws[(row * n + part) * 64 + dim], then
+// ml[(row * n + part) * 2 + {0, 1}] from float offset rows * n * 64;  sums  ws[(part * rows + row) * 64 + dim].
+struct SplitArgs {
+  int n;
+  float* ws;
+};
+
+__host__ __device__ __forceinline__ long split_fwd_floats(long rows_q, int n) { return rows_q * n * 66; }
+__host__ __device__ __forceinline__ long split_sum_floats(long rows, int n) { return rows * n * 64; }
+
+// (b, h, s) row of 64 floats per 16 lanes: out = sum over parts, in part order.
+__global__ __launch_bounds__(kBlock) void attn_sum_parts_kernel(const float* __restrict__ ws, int n, long rows,
+                                                                float* __restrict__ out, int H, int S, long sb, long ss,
+                                                                long sh) {
+  const long row = static_cast<long>(blockIdx.x) * (kBlock / 16) + threadIdx.x / 16;
+  if (row >= rows) return;
+  const int c4 = (threadIdx.x & 15) * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(ws + row * 64 + c4);
+  for (int p = 1; p < n; ++p) acc += *reinterpret_cast<const f32x4*>(ws + (p * rows + row) * 64 + c4);
+  const int s = static_cast<int>(row % S), head = static_cast<int>((row / S) % H);
+  const long b = row / (static_cast<long>(S) * H);
+  *reinterpret_cast<f32x4*>(out + b * sb + head * sh + static_cast<long>(s) * ss + c4) = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // On a CDNA4 SIMD vector instructions do not overlap the matrix pipe (tools/mfma_probe.hip: the tile loop's MFMAs alone
 // run at 65 cycles each, and every VALU instruction between them adds its own issue time, whatever the occupancy), so
@@ -175,19 +205,22 @@ __device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ row, 
   return b;
 }
 
-template <bool HAS_BIAS, bool STORE_S>
+template <bool HAS_BIAS, bool STORE_S, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v,
                                                              const float* __restrict__ bias, float* __restrict__ o,
                                                              float* __restrict__ lse, float* __restrict__ scores,
-                                                             AttnDims d, const int* __restrict__ key_hole) {
+                                                             AttnDims d, const int* __restrict__ key_hole,
+                                                             SplitArgs sp) {
   __shared__ float Kbuf[2][kTile * kKs];
   __shared__ __attribute__((aligned(16))) float Vbuf[2][kTile * kVi];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int nsp = SPLIT ? sp.n : 1;
+  const BlockCoord bc = block_coord(((d.Sq + 127) / 128) * nsp, d.B, d.H);
   const int b = bc.b, head = bc.head;
-  const int q0 = bc.blk * 128 + wave * kTile;
+  const int blk = SPLIT ? bc.blk / nsp : bc.blk, part = SPLIT ? bc.blk % nsp : 0;
+  const int q0 = blk * 128 + wave * kTile;
   const bool active = q0 < d.Sq;                           // a wave past the last query only helps staging the tiles
   const int qi = q0 + r;                                   // this lane's query
   const int ql = qi < d.Sq ? qi : d.Sq - 1;                // clamped for loads
@@ -208,20 +241,23 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   }
   f32x16 o0 = {0}, o1 = {0};                               // O^T[dim (+32)][query]
   float m = -INFINITY, mc = 0.0f, l = 0.0f;                // running max, the same times log2 e (0 while -inf), row sum
-  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  const int all_tiles = (d.Sk + kTile - 1) / kTile;
+  const int t_lo = SPLIT ? part * all_tiles / nsp : 0;       // this workgroup's key tiles [t_lo, n_tiles)
+  const int n_tiles = SPLIT ? (part + 1) * all_tiles / nsp : all_tiles;
   // keys [hole_lo, hole_hi) of this batch element are masked (-inf) for every head and query: the padded text tokens of
   // a question shorter than the batch's text length.  Wave-uniform (SGPRs); with it the additive bias can stay ONE
   // (1, H, S, S) slab shared by the batch instead of a per-sample (B, H, S, S) copy streamed from HBM by every call.
   const int hole_lo = key_hole ? key_hole[2 * b] : 0, hole_hi = key_hole ? key_hole[2 * b + 1] : 0;
   f32x16 bcur = {0};
-  if (HAS_BIAS && active) bcur = load_bias_tile(bp, 0);
+  if (HAS_BIAS && active) bcur = load_bias_tile(bp, t_lo * kTile);
   {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk), tv = load_tile_clamped(vb, d.v_ss, 0, d.Sk);
-    store_tile<kKs>(Kbuf[0], tk, 1.0f);
-    store_tile_interleaved(Vbuf[0], tv, 1.0f);
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, t_lo * kTile, d.Sk),
+                   tv = load_tile_clamped(vb, d.v_ss, t_lo * kTile, d.Sk);
+    store_tile<kKs>(Kbuf[t_lo & 1], tk, 1.0f);
+    store_tile_interleaved(Vbuf[t_lo & 1], tv, 1.0f);
   }
   __syncthreads();
-  for (int kt = 0; kt < n_tiles; ++kt) {
+  for (int kt = t_lo; kt < n_tiles; ++kt) {
     const int k0 = kt * kTile;
     const float* Ks = Kbuf[kt & 1] + r * kKs + 32 * h;
     const float* Vs = Vbuf[kt & 1] + 4 * h * kVi + 2 * r;
@@ -291,6 +327,25 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
     }
     __syncthreads();
   }
+  if (SPLIT) {                                   // partial: unnormalised accumulators + (max * log2 e, row sum)
+    if (qi < d.Sq) {
+      l = halves_sum(l);
+      const long row = (static_cast<long>(b) * d.H + head) * d.Sq + qi;
+      float* wo = sp.ws + (row * nsp + part) * 64;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dim = 8 * g + 4 * h;
+        *reinterpret_cast<f32x4*>(wo + dim) = f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(wo + 32 + dim) = f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+      }
+      if (h == 0) {
+        float* ml = sp.ws + static_cast<long>(d.B) * d.H * d.Sq * nsp * 64 + (row * nsp + part) * 2;
+        ml[0] = m == -INFINITY ? -INFINITY : mc;
+        ml[1] = l;
+      }
+    }
+    return;
+  }
   if (qi < d.Sq) {
     l = halves_sum(l);
     const float inv = 1.0f / l;
@@ -307,6 +362,31 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   }
 }
 
+
+// Forward parts -> o, lse: weights 2^(mc_part - max mc), the flash-decoding reduction, parts in index order.
+__global__ __launch_bounds__(kBlock) void attn_fwd_combine_kernel(const float* __restrict__ ws, int n,
+                                                                  float* __restrict__ o, float* __restrict__ lse,
+                                                                  AttnDims d) {
+  const long rows = static_cast<long>(d.B) * d.H * d.Sq;
+  const long row = static_cast<long>(blockIdx.x) * (kBlock / 16) + threadIdx.x / 16;
+  if (row >= rows) return;
+  const int c4 = (threadIdx.x & 15) * 4;
+  const float* ml = ws + rows * n * 64 + row * n * 2;
+  float top = -INFINITY;
+  for (int p = 0; p < n; ++p) top = fmaxf(top, ml[2 * p]);
+  float l = 0.0f;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int p = 0; p < n; ++p) {
+    const float w = ml[2 * p] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ml[2 * p] - top);
+    l += w * ml[2 * p + 1];
+    acc += *reinterpret_cast<const f32x4*>(ws + (row * n + p) * 64 + c4) * w;
+  }
+  const float inv = 1.0f / l;
+  const int qi = static_cast<int>(row % d.Sq), head = static_cast<int>((row / d.Sq) % d.H);
+  const long b = row / (static_cast<long>(d.Sq) * d.H);
+  *reinterpret_cast<f32x4*>(o + b * d.o_sb + head * d.o_sh + static_cast<long>(qi) * d.o_ss + c4) = acc * inv;
+  if ((threadIdx.x & 15) == 0) lse[row] = top * kLn2 + __logf(l);
+}
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // One workgroup = 4 waves = 128 queries of one (batch, head); loop over key tiles.  Query on the lane:
@@ -457,17 +537,20 @@ __global__ __launch_bounds__(kBlock) void attn_delta_kernel(const float* __restr
 // lane reads its 16 B-operand values back with ds_read_b32.  Same products in the same order: results are bitwise those
 // of the direct form.
 
+template <bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const float* __restrict__ k,
                                                                        const float* __restrict__ ds,
                                                                        float* __restrict__ dq, AttnDims d, long dq_sb,
-                                                                       long dq_ss, long dq_sh) {
+                                                                       long dq_ss, long dq_sh, SplitArgs sp) {
   __shared__ __attribute__((aligned(16))) float Kbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Dbuf[2][kTile * kDsStride];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
+  const int nsp = SPLIT ? sp.n : 1;
+  const BlockCoord bc = block_coord(((d.Sq + 127) / 128) * nsp, d.B, d.H);
   const int b = bc.b, head = bc.head;
-  const int Q0 = bc.blk * 128;
+  const int blk = SPLIT ? bc.blk / nsp : bc.blk, part = SPLIT ? bc.blk % nsp : 0;
+  const int Q0 = blk * 128;
   const int q0 = Q0 + wave * kTile;
   const int qi = q0 + r;
   const bool active = q0 < d.Sq;
@@ -477,12 +560,12 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
   // staging role of this thread: key row (t / 32) + 8 j of the tile, queries Q0 + 4 (t % 32) .. + 3
   const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
   const bool col_ok = Q0 + scol < pitch;                     // the last query block may reach beyond the row pitch
-  const float* sp = slab + static_cast<long>(srow) * pitch + (col_ok ? Q0 + scol : 0);
+  const float* dsrc = slab + static_cast<long>(srow) * pitch + (col_ok ? Q0 + scol : 0);
   auto load_ds = [&](int k0) {
     DsRegs t;
 #pragma unroll
     for (int j = 0; j < 4; ++j)                  // read exactly once
-      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + static_cast<long>(k0 + 8 * j) * pitch));
+      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dsrc + static_cast<long>(k0 + 8 * j) * pitch));
     return t;
   };
   auto store_ds = [&](float* buf, const DsRegs& t) {
@@ -490,15 +573,17 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
   };
   f32x16 dq0 = {0}, dq1 = {0};
-  const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  const int all_tiles = (d.Sk + kTile - 1) / kTile;
+  const int t_lo = SPLIT ? part * all_tiles / nsp : 0;
+  const int n_tiles = SPLIT ? (part + 1) * all_tiles / nsp : all_tiles;
   {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk);
-    const DsRegs td = load_ds(0);
-    store_tile_interleaved(Kbuf[0], tk, 1.0f);
-    store_ds(Dbuf[0], td);
+    const TileRegs tk = load_tile_clamped(kb, d.k_ss, t_lo * kTile, d.Sk);
+    const DsRegs td = load_ds(t_lo * kTile);
+    store_tile_interleaved(Kbuf[t_lo & 1], tk, 1.0f);
+    store_ds(Dbuf[t_lo & 1], td);
   }
   __syncthreads();
-  for (int kt = 0; kt < n_tiles; ++kt) {
+  for (int kt = t_lo; kt < n_tiles; ++kt) {
     const bool more = kt + 1 < n_tiles;
     const float* Kc = Kbuf[kt & 1] + 4 * h * kVi + 2 * r;
     const float* Dc = Dbuf[kt & 1] + 4 * h * kDsStride + wave * kTile + r;
@@ -526,7 +611,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
     __syncthreads();
   }
   if (qi < d.Sq) {
-    float* dp_ = dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
+    const long rows = static_cast<long>(d.B) * d.H * d.Sq;
+    float* dp_ = SPLIT ? sp.ws + (part * rows + (static_cast<long>(b) * d.H + head) * d.Sq + qi) * 64
+                       : dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dim = 8 * g + 4 * h;
@@ -622,7 +709,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const fl
 //   row index).  The per-query constants -LSE log2 e and delta ride in LDS next to the tiles, four consecutive
 //   accumulator rows per 16-byte read; the bias of this lane's key for the tile's query rows is 16 dword loads from a
 //   uniform row base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator.
-template <bool HAS_BIAS, bool STORE_DS, bool FROM_SCORES>
+template <bool HAS_BIAS, bool STORE_DS, bool FROM_SCORES, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
                                                                  const float* __restrict__ v,
@@ -634,7 +721,7 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
                                                                  AttnDims d, long dk_sb, long dk_ss, long dk_sh,
                                                                  long dv_sb, long dv_ss, long dv_sh, long go_sb,
                                                                  long go_ss, long go_sh, float* __restrict__ ds,
-                                                                 const float* __restrict__ scores) {
+                                                                 const float* __restrict__ scores, SplitArgs sp) {
   __shared__ __attribute__((aligned(16))) float Qbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Gbuf[2][kTile * kVi];
   __shared__ __attribute__((aligned(16))) float Lbuf[2][kTile], Dbuf[2][kTile];
@@ -644,7 +731,10 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   __shared__ __attribute__((aligned(16))) float Sbuf[FROM_SCORES ? 2 : 1][FROM_SCORES ? kTile * kDsStride : 4];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int r = lane & 31, h = lane >> 5;
-  const BlockCoord bc = block_coord((d.Sk + 127) / 128, d.B, d.H);
+  const int nsp = SPLIT ? sp.n : 1;
+  const BlockCoord bc0 = block_coord(((d.Sk + 127) / 128) * nsp, d.B, d.H);
+  const BlockCoord bc{bc0.b, bc0.head, SPLIT ? bc0.blk / nsp : bc0.blk};
+  const int part = SPLIT ? bc0.blk % nsp : 0;
   const int b = bc.b, head = bc.head;
   const int ki = bc.blk * 128 + wave * kTile + r;                     // this lane's key
   const bool active = bc.blk * 128 + wave * kTile < d.Sk;
@@ -678,7 +768,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     }
   }
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-  const int n_tiles = (d.Sq + kTile - 1) / kTile;
+  const int all_tiles = (d.Sq + kTile - 1) / kTile;
+  const int t_lo = SPLIT ? part * all_tiles / nsp : 0;       // this workgroup's query tiles [t_lo, n_tiles)
+  const int n_tiles = SPLIT ? (part + 1) * all_tiles / nsp : all_tiles;
   // per-query row constants of a tile: thread t < 32 carries (-lse log2 e, delta) of query q0 + t
   auto row_consts = [&](int q0, float& rl, float& rd) {
     const int qq = q0 + static_cast<int>(threadIdx.x);
@@ -722,21 +814,22 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
   };
   f32x16 bcur = {0};
-  if (kInit && !FROM_SCORES && active) bcur = load_bias(0);
+  if (kInit && !FROM_SCORES && active) bcur = load_bias(t_lo * kTile);
   {
-    const TileRegs tq = load_tile_clamped(qb, d.q_ss, 0, d.Sq), tg = load_tile_clamped(gb, go_ss, 0, d.Sq);
+    const int qs = t_lo * kTile, bi = t_lo & 1;
+    const TileRegs tq = load_tile_clamped(qb, d.q_ss, qs, d.Sq), tg = load_tile_clamped(gb, go_ss, qs, d.Sq);
     float rl, rd;
-    row_consts(0, rl, rd);
-    if (FROM_SCORES) store_scores(Sbuf[0], load_scores(0));
-    store_tile_interleaved(Qbuf[0], tq, d.scale);
-    store_tile_interleaved(Gbuf[0], tg, 1.0f);
+    row_consts(qs, rl, rd);
+    if (FROM_SCORES) store_scores(Sbuf[FROM_SCORES ? bi : 0], load_scores(qs));
+    store_tile_interleaved(Qbuf[bi], tq, d.scale);
+    store_tile_interleaved(Gbuf[bi], tg, 1.0f);
     if (threadIdx.x < kTile) {
-      Lbuf[0][threadIdx.x] = rl;
-      Dbuf[0][threadIdx.x] = rd;
+      Lbuf[bi][threadIdx.x] = rl;
+      Dbuf[bi][threadIdx.x] = rd;
     }
   }
   __syncthreads();
-  for (int qt = 0; qt < n_tiles; ++qt) {
+  for (int qt = t_lo; qt < n_tiles; ++qt) {
     const int q0 = qt * kTile;
     const float* Qr = Qbuf[qt & 1] + r * kVi + h;          // row read: Q[query r][32 h + s] at Qr[2 s]
     const float* Gr = Gbuf[qt & 1] + r * kVi + h;
@@ -820,8 +913,11 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     __syncthreads();
   }
   if (ki < d.Sk) {
-    float* pk = dk + b * dk_sb + head * dk_sh + static_cast<long>(ki) * dk_ss;
-    float* pv = dv + b * dv_sb + head * dv_sh + static_cast<long>(ki) * dv_ss;
+    const long rows = static_cast<long>(d.B) * d.H * d.Sk;
+    const long row = (static_cast<long>(b) * d.H + head) * d.Sk + ki;
+    float* pk = SPLIT ? sp.ws + (part * rows + row) * 64 : dk + b * dk_sb + head * dk_sh + static_cast<long>(ki) * dk_ss;
+    float* pv = SPLIT ? sp.ws + ((nsp + part) * rows + row) * 64
+                      : dv + b * dv_sb + head * dv_sh + static_cast<long>(ki) * dv_ss;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dim = 8 * g + 4 * h;
@@ -865,9 +961,26 @@ long vqa_attn_scores_floats(int B, int H, int Sq, int Sk) {
   return static_cast<long>(B) * H * sc_rows(Sq) * sc_pitch(Sk);
 }
 
+long vqa_attn_split_ws_floats(int B, int H, int Sq, int Sk, int nsplit) {
+  if (B < 0 || H <= 0 || Sq <= 0 || Sk <= 0 || nsplit < 1) return 0;
+  if (nsplit == 1) return 0;
+  const long rq = static_cast<long>(B) * H * Sq, rk = static_cast<long>(B) * H * Sk;
+  const long fwd = split_fwd_floats(rq, nsplit), dkv = 2 * split_sum_floats(rk, nsplit), dq = split_sum_floats(rq, nsplit);
+  return fwd > dkv ? (fwd > dq ? fwd : dq) : (dkv > dq ? dkv : dq);
+}
+
+static int check_split(int nsplit, const float* split_ws, int tiles, long wgs) {
+  if (nsplit < 1) return VQA_ERR_SHAPE;
+  if (nsplit == 1) return VQA_OK;
+  if (!split_ws) return VQA_ERR_NULL;
+  if (!aligned16(split_ws)) return VQA_ERR_ALIGN;
+  if (nsplit > tiles || wgs * nsplit > 2147483647L) return VQA_ERR_SHAPE;      // every part owns at least one tile
+  return VQA_OK;
+}
+
 int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bias, float* o, float* lse, float* scores,
                  int B, int H, int Sq, int Sk, const long* strides, const long* bias_strides, float scale,
-                 const int* key_hole, vqa_stream_t stream) {
+                 const int* key_hole, int nsplit, float* split_ws, vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !o || !lse || (bias && !bias_strides)) return VQA_ERR_NULL;
   AttnDims d{B, H, Sq, Sk, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], strides[6],
@@ -878,16 +991,30 @@ int vqa_attn_fwd(const float* q, const float* k, const float* v, const float* bi
     d.bias_sr = bias_strides[2];
     if (((d.bias_sb | d.bias_sh | d.bias_sr) & 3) || !aligned16(bias)) return VQA_ERR_ALIGN;
   }
-  const int rc = check_attn(q, k, v, d);
+  int rc = check_attn(q, k, v, d);
   if (rc != VQA_OK) return rc;
   if (!aligned16(o) || !aligned16(scores)) return VQA_ERR_ALIGN;
+  const long wgs = ((Sq + 127L) / 128) * H * B;
+  rc = check_split(nsplit, split_ws, (Sk + kTile - 1) / kTile, wgs);
+  if (rc != VQA_OK) return rc;
   if (B == 0) return VQA_OK;
-  const dim3 grid(static_cast<unsigned>(((Sq + 127) / 128) * H * B));
+  const dim3 grid(static_cast<unsigned>(wgs * nsplit));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bias && scores) attn_fwd_kernel<true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
-  else if (bias) attn_fwd_kernel<true, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
-  else if (scores) attn_fwd_kernel<false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
-  else attn_fwd_kernel<false, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole);
+  const SplitArgs sp{nsplit, split_ws};
+  if (nsplit > 1) {
+    if (bias && scores) attn_fwd_kernel<true, true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+    else if (bias) attn_fwd_kernel<true, false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+    else if (scores) attn_fwd_kernel<false, true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+    else attn_fwd_kernel<false, false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+    const long rows = static_cast<long>(B) * H * Sq;
+    attn_fwd_combine_kernel<<<dim3(static_cast<unsigned>((rows + kBlock / 16 - 1) / (kBlock / 16))), kBlock, 0, st>>>(
+        split_ws, nsplit, o, lse, d);
+    return launch_status();
+  }
+  if (bias && scores) attn_fwd_kernel<true, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+  else if (bias) attn_fwd_kernel<true, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+  else if (scores) attn_fwd_kernel<false, true><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
+  else attn_fwd_kernel<false, false><<<grid, kBlock, 0, st>>>(q, k, v, bias, o, lse, scores, d, key_hole, sp);
   return launch_status();
 }
 
@@ -900,7 +1027,7 @@ long vqa_attn_bwd_ws_floats(int B, int H, int Sq, int Sk) {
 int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bias, const float* o, const float* go,
                  const float* lse, const float* scores, float* delta, float* dq, float* dk, float* dv, float* ds_ws, int B,
                  int H, int Sq, int Sk, const long* strides, const long* bias_strides, const long* grad_strides,
-                 float scale, vqa_stream_t stream) {
+                 float scale, int nsplit, float* split_ws, vqa_stream_t stream) {
   clear_stale_error();
   if (!strides || !grad_strides || !o || !go || !lse || !delta || !dq || !dk || !dv || (bias && !bias_strides))
     return VQA_ERR_NULL;
@@ -925,10 +1052,39 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
   // the dS path addresses a (batch, head) slab of either workspace with 32-bit lane offsets
   if (ds_ws && (ds_rows(Sk) * ds_pitch(Sq) >= 2147483647L || sc_rows(Sq) * sc_pitch(Sk) >= 2147483647L))
     return VQA_ERR_SHAPE;
+  {
+    const int tq = (Sq + kTile - 1) / kTile, tk = (Sk + kTile - 1) / kTile;
+    const long big = (((Sq > Sk ? Sq : Sk) + 127L) / 128) * H * B;
+    const int rs = check_split(nsplit, split_ws, tq < tk ? tq : tk, big);
+    if (rs != VQA_OK) return rs;
+    if (nsplit > 1 && !(ds_ws && scores)) return VQA_ERR_SHAPE;      // the split forms exist for the saved-scores backward
+  }
   if (B == 0) return VQA_OK;
   const long* g = grad_strides;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 gq(static_cast<unsigned>(((Sq + 127) / 128) * H * B)), gk(static_cast<unsigned>(((Sk + 127) / 128) * H * B));
+  const SplitArgs sp{nsplit, split_ws};
+  const dim3 gq(static_cast<unsigned>(((Sq + 127) / 128) * H * B * nsplit)),
+      gk(static_cast<unsigned>(((Sk + 127) / 128) * H * B * nsplit));
+  if (ds_ws && nsplit > 1) {                     // small batches: the loops of both kernels cut into nsplit parts
+    const long rq = static_cast<long>(B) * H * Sq, rk = static_cast<long>(B) * H * Sk;
+    const int per = kBlock / 16;
+    attn_delta_kernel<<<dim3(static_cast<unsigned>((rq + per - 1) / per)), kBlock, 0, st>>>(o, go, delta, d, g[0], g[1], g[2]);
+    if (bias)
+      attn_bwd_dkv_kernel<true, true, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
+                                                                         g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
+                                                                         scores, sp);
+    else
+      attn_bwd_dkv_kernel<false, true, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
+                                                                          g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
+                                                                          ds_ws, scores, sp);
+    const dim3 gsk(static_cast<unsigned>((rk + per - 1) / per)), gsq(static_cast<unsigned>((rq + per - 1) / per));
+    attn_sum_parts_kernel<<<gsk, kBlock, 0, st>>>(split_ws, nsplit, rk, dk, H, Sk, g[6], g[7], g[8]);
+    attn_sum_parts_kernel<<<gsk, kBlock, 0, st>>>(split_ws + split_sum_floats(rk, nsplit), nsplit, rk, dv, H, Sk, g[9],
+                                                  g[10], g[11]);
+    attn_bwd_dq_staged_kernel<true><<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5], sp);   // after the sums: same ws
+    attn_sum_parts_kernel<<<gsq, kBlock, 0, st>>>(split_ws, nsplit, rq, dq, H, Sq, g[3], g[4], g[5]);
+    return launch_status();
+  }
   if (ds_ws) {                                   // 5 products: delta pre-pass, dK / dV (+ dS^T store), dQ from dS^T
     const long n_rows = static_cast<long>(B) * H * Sq;
     const long blocks = (n_rows + kBlock / 16 - 1) / (kBlock / 16);
@@ -937,36 +1093,36 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
     if (scores && bias)                          // saved scores already include the bias
       attn_bwd_dkv_kernel<true, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
                                                                    g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
-                                                                   scores);
+                                                                   scores, sp);
     else if (scores)
       attn_bwd_dkv_kernel<false, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
                                                                     g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
-                                                                    scores);
+                                                                    scores, sp);
     else if (bias)
       attn_bwd_dkv_kernel<true, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
                                                                     g[8], g[9], g[10], g[11], g[0], g[1], g[2], ds_ws,
-                                                                    nullptr);
+                                                                    nullptr, sp);
     else
       attn_bwd_dkv_kernel<false, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
                                                                      g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
-                                                                     ds_ws, nullptr);
+                                                                     ds_ws, nullptr, sp);
 #ifdef VQA_TUNING
     if (!g_attn_dq_staged) attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
     else
 #endif
-    attn_bwd_dq_staged_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
+    attn_bwd_dq_staged_kernel<false><<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5], sp);
   } else if (bias) {                             // no workspace: 7 products, both kernels recompute the scores
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
                                                      g[2]);
     attn_bwd_dkv_kernel<true, false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
                                                                    g[8], g[9], g[10], g[11], g[0], g[1], g[2], nullptr,
-                                                                   nullptr);
+                                                                   nullptr, sp);
   } else {
     attn_bwd_dq_kernel<false><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0],
                                                       g[1], g[2]);
     attn_bwd_dkv_kernel<false, false, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6], g[7],
                                                                     g[8], g[9], g[10], g[11], g[0], g[1], g[2], nullptr,
-                                                                    nullptr);
+                                                                    nullptr, sp);
   }
   return launch_status();
 }

@@ -367,7 +367,7 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
   return launch_status();
 }
 
-int vqa_abi_version(void) { return 3; }
+int vqa_abi_version(void) { return 4; }
 
 const char* vqa_error_string(int code) {
   switch (code) {

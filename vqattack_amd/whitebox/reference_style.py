@@ -23,42 +23,61 @@ import torch
 
 class VlmoReferenceClosures:
     """``self.batch``: ``text_ids`` / ``text_masks`` (1, L) and, for the MLM closure, ``text_ids_mlm`` /
-    ``text_mask_mlm`` -- the keys the reference's closures read."""
+    ``text_mask_mlm`` -- the keys the reference's closures read.
+
+    What depends on the text batch only is taken ONCE per text batch (keyed on the mask tensor's address and in-place
+    version), not once per forward as in the reference: the index of the real text tokens (``torch.where``: a
+    device->host read, vlmo_module.py:1441) and the per-layer attention masks (``get_rel_pos_bias`` + key padding,
+    :1416,88-118).  With a prefix mask (``[CLS] words [SEP] pad...``: what a tokenizer produces) the padded columns are
+    not run through the encoder at all -- they are masked keys and dropped rows, so no result changes -- and the packed
+    per-token tensor is the stacked maps themselves (no gather, no ``cat``).  The closures then contain no host read and
+    can be captured into a hipGraph: ``pgd(..., graph=True)``; ``capturable`` says so."""
+
+    capturable = True
 
     def __init__(self, model, batch):
         self.model, self.batch = model, batch
-        self._real = None
+        self._text = None
 
-    def _real_text(self, text_masks):
-        """``torch.where(text_masks[0] == 1)`` (vlmo_module.py:1441) -- a device->host read (the index list's length).
-        The reference pays it in every forward; here it is taken once per text batch (keyed on the mask tensor and its
-        in-place version), which also makes the closure capturable into a hipGraph (``graph=True``)."""
+    def _text_state(self, text_masks):
         key = (text_masks.data_ptr(), text_masks._version, tuple(text_masks.shape))
-        if self._real is None or self._real[0] != key:
-            self._real = (key, torch.where(text_masks[0] == 1)[0])
-        return self._real[1]
+        if self._text is None or self._text[0] != key:
+            m = text_masks[0].bool()
+            n = int(m.sum())                                                   # the one host read per text batch
+            prefix = bool(m[:n].all())
+            real = None if prefix else torch.where(text_masks[0] == 1)[0]
+            keep = n if prefix else text_masks.shape[1]
+            bias = self.model.attention_bias(text_masks[:, :keep])
+            self._text = (key, keep, real, bias)
+        return self._text[1:]
 
-    def _packed(self, feats, states, text_masks):
-        target = torch.stack(feats, axis=1)                                  # (1, depth + 1, L + N, D)
-        image_part = target[0, :, self.model.cfg.max_text_len:]              # the reference's literal 40
-        per_token = torch.cat([target[0, :, self._real_text(text_masks)], image_part], axis=1)
-        return self.model.pooled(states), target[0, :, 0, :], per_token
+    def _encode(self, image, text_embeds, text_masks):
+        keep, real, bias = self._text_state(text_masks)
+        feats, states = self.model.encode(image, text_embeds[:, :keep], text_masks[:, :keep], bias)
+        target = torch.stack(feats, axis=1)                                  # (1, depth + 1, keep + N, D)
+        if real is None:                                                     # prefix mask: rows = real text + image
+            per_token = target[0]
+        else:
+            per_token = torch.cat([target[0, :, real], target[0, :, self.model.cfg.max_text_len:]], axis=1)
+        return states, self.model.pooled(states), target[0, :, 0, :], per_token, keep
 
     def pgd_attack(self, x):
         ids, masks = self.batch["text_ids"], self.batch["text_masks"]
-        feats, states = self.model.encode(x, self.model.text_embeddings(ids), masks)
-        return list(self._packed(feats, states, masks))
+        _, pooled, per_layer_cls, per_token, _ = self._encode(x, self.model.text_embeddings(ids), masks)
+        return [pooled, per_layer_cls, per_token]
 
     def pgd_attack_vl(self, x):
-        masks = self.batch["text_masks"]
-        feats, states = self.model.encode(x[0], x[1], masks)
-        return list(self._packed(feats, states, masks))
+        _, pooled, per_layer_cls, per_token, _ = self._encode(x[0], x[1], self.batch["text_masks"])
+        return [pooled, per_layer_cls, per_token]
 
     def pgd_mlm_attack(self, x):
         ids, masks = self.batch["text_ids_mlm"], self.batch["text_mask_mlm"]
-        feats, states = self.model.encode(x, self.model.text_embeddings(ids), masks)
-        _, per_layer_cls, per_token = self._packed(feats, states, masks)
-        return [self.model.mlm_score(states[:, :self.model.cfg.max_text_len]), per_layer_cls, per_token]
+        states, _, per_layer_cls, per_token, keep = self._encode(x, self.model.text_embeddings(ids), masks)
+        logits = self.model.mlm_score(states[:, :keep])
+        full = self.model.cfg.max_text_len
+        if keep < full:             # the reference's (1, 40, V) contract: labels at the dropped positions are ignore_index
+            logits = torch.nn.functional.pad(logits, (0, 0, 0, full - keep))
+        return [logits, per_layer_cls, per_token]
 
     def Gen_ori_feats(self, image):
         with torch.no_grad():
@@ -66,6 +85,11 @@ class VlmoReferenceClosures:
 
 
 class AlbefReferenceClosures:
+    """ALBEF's closures (adv_attack.py:111-126,130-140,208-214).  Capturable as well: the per-forward random token masking
+    (model_pretrain.py:130-132) is drawn on the device from torch's graph-safe generator when no masking seed is set."""
+
+    capturable = True
+
     def __init__(self, model, batch):
         self.model, self.batch = model, batch
 
