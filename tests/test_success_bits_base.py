@@ -43,8 +43,10 @@ FIXTURES = [("asr_base_vlmo.json", "vlmo"), ("asr_base_albef.json", "albef")]
 TIE = 1e-3          # oracle decision margin (gap between the victim's two leading answers) below which a sample is a tie
 RESULTS = {}        # fixture -> dict(flavor, n, want bits, got bits, margins, sample ids), for the pooled test
 FULL = os.environ.get("VQA_ASR_FULL", "") not in ("", "0")
-SUBSET = dict(vlmo=64, albef=32)     # driver-run suite: the first K samples of every fixture file ...
-SUBSET_SMALL = dict(vlmo=16, albef=8)    # ... of the many small draws (< 100 samples, tools/asr_box_round.sh): one batch each
+# driver-run suite: the first K samples of every fixture file (round 6: 1 775 of the pool's 3 366 samples, ~ 4.5 min of
+# the suite's 15-minute limit; rounds 4-5: 760); the whole pool runs with VQA_ASR_FULL=1 (profiles/r05/asr_full_report.json)
+SUBSET = dict(vlmo=150, albef=96)
+SUBSET_SMALL = dict(vlmo=32, albef=16)   # ... of the many small draws (< 100 samples, tools/asr_box_round.sh)
 _MODELS = {}        # (flavor, answer-set size of the ALBEF victim) -> (white on the GPU, black on the GPU, adapters, cfg)
 
 
