@@ -14,7 +14,7 @@ import os
 
 import yaml
 
-from _common import file_source, finish, init_distributed, load_checkpoint, seed_everything
+from _common import file_source, finish, init_distributed, load_checkpoint, mlm_proposer, seed_everything
 
 import torch.distributed as dist  # noqa: E402  (after _common: it sets the HSA IPC mode before torch loads)
 
@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--tables_dir", default="", help="directory of the reference's in-tree *.txt tables")
     ap.add_argument("--checkpoint", default="", help="pre-trained ALBEF checkpoint -> white box (adv_attack.py:83)")
     ap.add_argument("--checkpoint_vqa", default="", help="VQA fine-tuned checkpoint -> victim (adv_attack.py:96)")
+    ap.add_argument("--mlm_checkpoint", default="", help="BertForMaskedLM state dict -> candidate proposer (adv_attack.py:110)")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
     rank, world, device = init_distributed()
@@ -60,6 +61,7 @@ def main():
         black = FrozenAlbef.finetuned_from(white, seed=args.seed + 1).to(device)
     out_dir = os.path.join(args.output_dir, cfg.get("attack_dir", "attack_dir")) if args.output_dir else None
     text_len = min(cfg["text_len"], 8 if args.tiny else 512)
+    proposer, banned = mlm_proposer(args.mlm_checkpoint, args.vocab_file, device)
     source = None
     if args.questions:
         source = file_source("albef", args.questions, args.image_root or cfg.get("vqa_root", ""), text_len,
@@ -68,7 +70,7 @@ def main():
                     cfg["batch_size_test"], mcfg.image_size, text_len, device,
                     rank, world, joint=not args.image_only, save_dir=out_dir, seed=args.seed,
                     max_words=4 if args.tiny else 12, dual_every=args.dual_every, mixed=args.mixed,
-                    force_collective=dist.is_initialized(), source=source)
+                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned)
     finish(rank, world, res, os.path.join(args.output_dir, "adv_txt.json") if args.output_dir else None)
 
 

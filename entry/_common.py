@@ -55,6 +55,21 @@ def file_source(flavor, questions, image_root, text_len, image_size, vocab_file=
     return VqaFilePairs(questions, image_root, flavor, text_len, image_size, tokenizer=tok, tables=tables, joint=joint)
 
 
+def mlm_proposer(checkpoint, vocab_file, device):
+    """The reference's candidate proposer, ``BertForMaskedLM.from_pretrained('bert-base-uncased')`` (adv_attack.py:110),
+    from a local HF state dict, + the ids it may never propose (``##`` pieces and stop words, adv_attack.py:253-258).
+    Returns ``(mlm_logits_fn, banned_ids)``; ``(None, None)`` without a checkpoint (the white box's own MLM head then
+    proposes)."""
+    if not checkpoint:
+        return None, None
+    from vqattack_amd.attack.dataset import DEFAULT_STOP_WORDS
+    from vqattack_amd.attack.proposer import BertMlmProposer, banned_ids
+    from vqattack_amd.attack.wordpiece import WordPiece
+    model = BertMlmProposer.from_hf_state_dict(load_checkpoint(checkpoint)).to(device)
+    banned = banned_ids(WordPiece(vocab_file).tokens, DEFAULT_STOP_WORDS).to(device) if vocab_file else None
+    return model, banned
+
+
 def load_checkpoint(path):
     """``torch.load(path, map_location='cpu')`` of a reference checkpoint (adv_attack.py:83,96; vlmo_module.py:690) --
     tensors only (``weights_only``): a checkpoint is data, never code."""

@@ -5,7 +5,8 @@
 
 Named configs and ``key=value`` overrides are parsed like sacred's ``with`` clause; only the keys the attack reads are
 known (``vlmo/config.py:20-90,283-337``): image_size, max_text_len, per_gpu_batchsize, model arch, seed, test_only, and
-the two checkpoint paths ``pretrain_path`` (white box) / ``load_path`` (VQA victim) (``config.py:83-87``).
+the two checkpoint paths ``pretrain_path`` (white box) / ``load_path`` (VQA victim) (``config.py:83-87``);
+``mlm_checkpoint=`` is a local ``BertForMaskedLM`` state dict for the candidate proposer (``adv_attack.py:110``).
 
 File inputs instead of the synthetic set (``attack/dataset.py``): ``questions=`` (VQA annotation json), ``image_root=``,
 ``vocab_file=`` (BERT vocab.txt, for textual questions / tables), ``tables_dir=`` (the reference's in-tree ``*.txt``
@@ -16,7 +17,7 @@ one is attacked; ``attack_dir=`` receives ``<question_id>.pt`` and ``adv_txt.jso
 import os
 import sys
 
-from _common import file_source, finish, init_distributed, load_checkpoint, seed_everything
+from _common import file_source, finish, init_distributed, load_checkpoint, mlm_proposer, seed_everything
 
 import torch.distributed as dist  # noqa: E402  (after _common: it sets the HSA IPC mode before torch loads)
 
@@ -29,7 +30,7 @@ NAMED = {
 }
 DEFAULTS = dict(arch="vlmo_base", image_size=384, max_text_len=40, per_gpu_batchsize=64, seed=1, test_only=True,
                 n_samples=128, image_only=False, attack_dir="", dual_every=0, mixed=False, questions="", image_root="",
-                vocab_file="", tables_dir="", pretrain_path="", load_path="")
+                vocab_file="", tables_dir="", pretrain_path="", load_path="", mlm_checkpoint="")
 
 
 def parse(argv):
@@ -74,6 +75,7 @@ def main():
             image_size=cfg["image_size"], max_text_len=cfg["max_text_len"])
         white = vlmo.FrozenVlmo(mcfg, seed=cfg["seed"]).to(device)
         black = vlmo.FrozenVlmo.finetuned_from(white, seed=cfg["seed"] + 1).to(device)
+    proposer, banned = mlm_proposer(cfg["mlm_checkpoint"], cfg["vocab_file"], device)   # HF bert-base-uncased MLM
     source = None
     if cfg["questions"]:
         source = file_source("vlmo", cfg["questions"], cfg["image_root"], mcfg.max_text_len, mcfg.image_size,
@@ -82,7 +84,7 @@ def main():
                     mcfg.image_size, mcfg.max_text_len, device, rank, world, joint=not cfg["image_only"],
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],
                     max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"],
-                    force_collective=dist.is_initialized(), source=source)
+                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned)
     # adversarial images <qid>.pt and the adversarial-text json go to attack_dir (vlmo_module.py:166-167,2059-2062,2095-2097)
     finish(rank, world, res, os.path.join(cfg["attack_dir"], "adv_txt.json") if cfg["attack_dir"] else None)
 

@@ -70,7 +70,8 @@ def synthetic_images(qids, image_size, device):
 
 def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text_len, device, rank=0, world=1,
               config=None, joint=True, save_dir=None, log_every=50, seed=0, max_words=12, dual_every=0, mixed=False,
-              attack=None, force_collective=False, collective_device=None, progress=None, source=None):
+              attack=None, force_collective=False, collective_device=None, progress=None, source=None,
+              mlm_logits_fn=None, banned_ids=None):
     """Returns ``dict(asr, n_total, n_local, seconds, examples_per_sec_local, gradient_steps, n_batches, mean_batch,
     global_steps, batch_global_steps, gather_seconds, adv_text, collectives, input_seconds, input_blocked_seconds,
     writer_seconds)`` on every rank: ``seconds`` is this rank's attack + scoring time (device drained, the ``.pt`` writer
@@ -102,7 +103,8 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
     mine = shard_indices(n_samples, rank, world)
     device = torch.device(device)
     if attack is None:
-        attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig())
+        attack = BatchedVQAttack(adapters, flavor, white.embedding_tables(), config or AttackConfig(),
+                                 banned_ids=banned_ids)
     # collective_device: where the gathered tensors live -- the compute device under RCCL (default); the host when several
     # ranks rehearse on ONE GPU over gloo (bench.py, VQA_DIST_BACKEND=gloo)
     ledger = SuccessLedger(world, rank, collective_device if collective_device is not None else device,
@@ -140,12 +142,13 @@ def run_sweep(flavor, white, black, adapters, n_samples, batch, image_size, text
         clean = black.vqa_answer(images, tid, tmask)
         if key == -2:
             batch_tasks = [tasks[q] for q in index]
-            res = attack.attack_mixed(images, tid, tmask, tatt,
+            res = attack.attack_mixed(images, tid, tmask, tatt, mlm_logits_fn=mlm_logits_fn,
                                       tasks=batch_tasks if any(t.old_alg == 0 for t in batch_tasks) else None)
         elif is_dual:
-            res = attack.attack_batch(images, tid, tmask, tatt, dual=True, tasks=[tasks[q] for q in index])
+            res = attack.attack_batch(images, tid, tmask, tatt, mlm_logits_fn=mlm_logits_fn, dual=True,
+                                      tasks=[tasks[q] for q in index])
         else:
-            res = attack.attack_batch(images, tid, tmask, tatt)
+            res = attack.attack_batch(images, tid, tmask, tatt, mlm_logits_fn=mlm_logits_fn)
         after = black.vqa_answer(res.adv_images, res.adv_text_ids, tmask)
         ledger.record(after != clean, sample_ids=index)
         # per-sample gradient steps, the same quantity on the bucketed and on the mixed path
