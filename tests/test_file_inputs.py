@@ -267,11 +267,22 @@ def test_entry_run_on_files_equals_the_attack_fed_the_oracles_tensors(tmp_path, 
     sd = ec.seeded_state_dict(rec["listing"], rec["seed"])
     ckpt = str(tmp_path / "vlmo_tiny_pretrain.pt")
     torch.save({"state_dict": sd}, ckpt)
+    # the candidate proposer: a BertForMaskedLM state dict in the transformers library's own key names (adv_attack.py:110)
+    tf = pytest.importorskip("transformers")
+    torch.manual_seed(11)
+    hf = tf.BertForMaskedLM(tf.BertConfig(vocab_size=len(text_meta["vocab"]), hidden_size=128, num_hidden_layers=2,
+                                          num_attention_heads=2, intermediate_size=512, max_position_embeddings=64))
+    with torch.no_grad():
+        for name, prm in hf.named_parameters():
+            if prm.dim() == 2 and "embeddings" not in name:
+                prm.normal_(0.0, prm.shape[1] ** -0.5)
+    mlm_ckpt = str(tmp_path / "bert_mlm.pt")
+    torch.save(hf.state_dict(), mlm_ckpt)
     attack_dir = str(tmp_path / "attack_dir_VLMO_BASE")
     out = str(tmp_path / "run.out")
     argv = ["with", "image_size=32", "max_text_len=40", "per_gpu_batchsize=16", "mixed=True", "questions=" + qfile,
             "image_root=" + str(tmp_path), "vocab_file=" + vocab, "tables_dir=" + tables_dir, "pretrain_path=" + ckpt,
-            "attack_dir=" + attack_dir, "seed=3"]
+            "mlm_checkpoint=" + mlm_ckpt, "attack_dir=" + attack_dir, "seed=3"]
     ctx = multiprocessing.get_context("forkserver")
     p = ctx.Process(target=_entry_run, args=(out, argv))
     p.start()
@@ -302,8 +313,13 @@ def test_entry_run_on_files_equals_the_attack_fed_the_oracles_tensors(tmp_path, 
     src.images, src.prefetch = oracle_images, (lambda indices: None)
     ref_dir = str(tmp_path / "ref_dir")
     torch.manual_seed(3)                             # entry/run.py seeds torch with seed + rank (VQA.py:74-77)
+    from vqattack_amd.attack.proposer import BertMlmProposer, banned_ids
+    proposer = BertMlmProposer.from_hf_state_dict(torch.load(mlm_ckpt, weights_only=True)).to(dev)
+    banned = banned_ids(WordPiece(vocab).tokens, ds.DEFAULT_STOP_WORDS).to(dev)
     res = run_sweep("vlmo", white, black, VlmoAttackAdapters(white), 0, 16, 32, 40, dev, mixed=True, save_dir=ref_dir,
-                    log_every=0, source=src, config=AttackConfig())
+                    log_every=0, source=src, config=AttackConfig(), mlm_logits_fn=proposer, banned_ids=banned)
+    assert any(row != src.ids[i].tolist() for i, row in enumerate(res["adv_text"][str(q)] for q in src.qids)), \
+        "the proposer's candidates never led to a substitution: the text side of the test would be vacuous"
     assert res["n_total"] == len(keep) and res["skipped"] == n - len(keep)
     assert {k: v for k, v in res["adv_text"].items()} == adv_txt
     for q in keep:
