@@ -709,6 +709,8 @@ def reference_style_leg(flavor, white, cfg, text_len, pgd_steps, reps=2):
         from vqattack_amd.whitebox.albef import AlbefAttackAdapters as Adapters
     bundled = BatchedVQAttack(Adapters(white), flavor, white.embedding_tables(),
                               AttackConfig(budget=pgd_steps, random_start=True, sanity_checks=True))
+    bundled_graph = BatchedVQAttack(Adapters(white), flavor, white.embedding_tables(),
+                                    AttackConfig(budget=pgd_steps, random_start=True, sanity_checks=True, use_graph=True))
     words = torch.zeros_like(ids, dtype=torch.bool)
 
     def timed(fn):
@@ -722,6 +724,10 @@ def reference_style_leg(flavor, white, cfg, text_len, pgd_steps, reps=2):
     ms_ref = timed(reference_call)
     ms_eager = timed(lambda: reference_call(False)) if replay else ms_ref
     ms_bundled = timed(lambda: bundled.attack_batch(image, ids, masks, words))
+    try:
+        ms_bundled_graph = round(timed(lambda: bundled_graph.attack_batch(image, ids, masks, words)), 3)
+    except Exception as exc:             # noqa: BLE001  (an auxiliary figure must not lose the leg)
+        ms_bundled_graph = "{}: {}".format(type(exc).__name__, str(exc)[:120])
     return dict(what="the reference's own call at its own batch size 1: its pgd_attack member (packed plain tensors, [0] "
                      "indexing) as model_fn through the drop-in projected_gradient_descent, {} steps, time=0, "
                      "sanity_checks on".format(pgd_steps),
@@ -732,6 +738,7 @@ def reference_style_leg(flavor, white, cfg, text_len, pgd_steps, reps=2):
                     "iterations 1.. from one hipGraph (graph=True, an extension kwarg); at batch 1 the attention kernels cut "
                     "their tile loops into parts (attention.loop_split) so that 12 heads fill the chip",
                 bundled_adapters_ms_per_pgd_iteration=round(ms_bundled, 3),
+                bundled_adapters_graph_ms_per_pgd_iteration=ms_bundled_graph,
                 bundled_adapters_examples_per_sec=round(1e3 / (ms_bundled * pgd_steps), 3),
                 loss_launches_per_iteration=2, note="wall clock incl. the one host read per PGD call; the two (output, "
                 "target) pairs of the packed form have different shapes (per-layer [CLS] rows / all token rows; text / "
