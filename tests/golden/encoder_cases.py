@@ -37,6 +37,17 @@ ALBEF_CASES = {
                             vocab=997, text_len=16, text_lens=(16, 10), seed=203, store_weights=False),
 }
 
+# The VQA victim (``ALBEF`` of models/model_vqa.py: ViT + fusion BERT + a causal answer decoder with cross-attention in
+# every layer, answers RANKED by ``rank_answer``), in the fine-tuned checkpoint's key layout (``text_encoder.*`` without
+# ``.bert``, ``text_decoder.bert.*``, ``text_decoder.cls.*``)
+ALBEF_VQA_CASES = {
+    "albef_vqa_tiny": dict(dim=64, heads=4, vit_depth=2, bert_depth=2, fusion_layer=1, dec_depth=2, image_size=32, patch=8,
+                           vocab=997, text_len=12, text_lens=(12, 7), n_answers=13, answer_len=5, k_test=5, seed=301),
+    "albef_vqa_head64": dict(dim=128, heads=2, vit_depth=2, bert_depth=2, fusion_layer=1, dec_depth=2, image_size=64,
+                             patch=16, vocab=997, text_len=12, text_lens=(9, 12), n_answers=13, answer_len=5, k_test=5,
+                             seed=302),
+}
+
 SAMPLE_ROWS = 16          # rows of a base-width feature map kept in the fixture
 SAMPLE_GRAD = 4096        # elements of a base-width image gradient kept
 
@@ -112,6 +123,19 @@ def case_inputs(name, case, flavor):
     mlm_ids = ids.clone()
     mlm_ids[:, 3] = 103
     return dict(image=image, ids=ids, masks=masks, mlm_ids=mlm_ids)
+
+
+def answer_list(case):
+    """Seeded synthetic answer list (n, L) int64: ``[BOS = 1] pieces [SEP = 102] pad = 0`` with 1 .. L - 2 pieces."""
+    g = torch.Generator().manual_seed(case["seed"] + 6000)
+    n, length = case["n_answers"], case["answer_len"]
+    ans = torch.zeros(n, length, dtype=torch.long)
+    ans[:, 0] = 1
+    for i in range(n):
+        k = int(torch.randint(1, length - 1, (1,), generator=g))
+        ans[i, 1:1 + k] = torch.randint(200, case["vocab"], (k,), generator=g)
+        ans[i, 1 + k] = 102
+    return ans
 
 
 def functional_weights(shapes, seed):

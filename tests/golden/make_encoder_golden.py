@@ -296,6 +296,107 @@ def albef_case(name, case, arrays, meta):
     meta[name] = rec
 
 
+# ---- ALBEF VQA victim: fusion encoder + answer decoder + rank_answer ------------------------------------------------
+def build_ref_albef_vqa(case):
+    """``ALBEF`` of models/model_vqa.py:12-45 from the reference's classes: ``visual_encoder`` (VisionTransformer),
+    ``text_encoder`` (BertModel: embeddings + encoder, fusion from ``fusion_layer``), ``text_decoder`` (BertLMHeadModel:
+    ``bert.embeddings`` + ``bert.encoder`` with ``fusion_layer = 0`` and ``num_hidden_layers = 6`` there, model_vqa.py:30-33,
+    + ``cls``), under the attribute names that give the fine-tuned checkpoint's state-dict keys."""
+    vit = rx.module_items(ALBEF_VIT, ["Mlp", "Attention", "Block", "VisionTransformer"],
+                          extra_globals=dict(partial=functools.partial, PatchEmbed=_TimmPatchEmbed,
+                                             trunc_normal_=nn.init.trunc_normal_))
+    xb = rx.module_items(rx.ALBEF_XBERT, XBERT_CLASSES, extra_globals=_hf_globals())
+    d = case["dim"]
+    common = dict(vocab_size=case["vocab"], hidden_size=d, max_position_embeddings=64, num_attention_heads=case["heads"],
+                  intermediate_size=4 * d, encoder_width=d, position_embedding_type="absolute")
+    enc_cfg = _bert_config(num_hidden_layers=case["bert_depth"], fusion_layer=case["fusion_layer"], **common)
+    dec_cfg = _bert_config(num_hidden_layers=case["dec_depth"], fusion_layer=0, **common)
+    m = nn.Module()
+    m.visual_encoder = vit["VisionTransformer"](img_size=case["image_size"], patch_size=case["patch"], embed_dim=d,
+                                                depth=case["vit_depth"], num_heads=case["heads"], mlp_ratio=4, qkv_bias=True,
+                                                norm_layer=functools.partial(nn.LayerNorm, eps=1e-6))
+    m.text_encoder = nn.Module()
+    m.text_encoder.embeddings = xb["BertEmbeddings"](enc_cfg)
+    m.text_encoder.encoder = xb["BertEncoder"](enc_cfg)
+    m.text_decoder = nn.Module()
+    m.text_decoder.bert = nn.Module()
+    m.text_decoder.bert.embeddings = xb["BertEmbeddings"](dec_cfg)
+    m.text_decoder.bert.encoder = xb["BertEncoder"](dec_cfg)
+    m.text_decoder.cls = xb["BertOnlyMLMHead"](dec_cfg)
+    m.text_decoder.cls.predictions.decoder.weight = m.text_decoder.bert.embeddings.word_embeddings.weight
+    return m.eval()
+
+
+def _ext(mask, dtype):
+    return (1.0 - mask[:, None, None, :].to(dtype)) * -10000.0
+
+
+def _ref_question_states(m, image, ids, masks):
+    """``ALBEF.forward(train=False)`` up to the question states (model_vqa.py:122-128; BertModel.forward glue)."""
+    image_embeds, _ = m.visual_encoder(image)
+    emb = m.text_encoder.embeddings(input_ids=ids)
+    img_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long)
+    out, _ = m.text_encoder.encoder(emb, attention_mask=_ext(masks, emb.dtype), encoder_hidden_states=image_embeds,
+                                    encoder_attention_mask=_ext(img_atts, emb.dtype), return_dict=True, mode="multi_modal")
+    return out.last_hidden_state
+
+
+def _ref_text_decoder(m):
+    """``BertLMHeadModel.forward`` (xbert.py:1219-1330) around the reference's decoder classes: causal x padding mask
+    (``get_extended_attention_mask`` :905-943 with ``is_decoder``), inverted encoder mask, shifted per-token CE summed over
+    the sequence (``reduction='none'``)."""
+    import torch.nn.functional as F
+
+    def text_decoder(input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
+                     return_dict=True, reduction="none"):
+        n, length = input_ids.shape
+        atts = torch.ones_like(input_ids) if attention_mask is None else attention_mask
+        emb = m.text_decoder.bert.embeddings(input_ids=input_ids)
+        seq = torch.arange(length)
+        causal = (seq[None, None, :].repeat(n, length, 1) <= seq[None, :, None]).to(atts.dtype)
+        ext = causal[:, None, :, :] * atts[:, None, None, :]
+        ext = (1.0 - ext.to(emb.dtype)) * -10000.0
+        out, _ = m.text_decoder.bert.encoder(emb, attention_mask=ext, encoder_hidden_states=encoder_hidden_states,
+                                             encoder_attention_mask=_ext(encoder_attention_mask, emb.dtype),
+                                             return_dict=True, mode="multi_modal")
+        res = rx.namespace(logits=m.text_decoder.cls(out.last_hidden_state), loss=None)
+        if labels is not None:
+            shifted = res.logits[:, :-1, :].contiguous()
+            lab = labels[:, 1:].contiguous()
+            loss = F.cross_entropy(shifted.view(-1, shifted.shape[-1]), lab.view(-1), reduction=reduction)
+            res.loss = loss.view(res.logits.size(0), -1).sum(1)
+        return res
+    return text_decoder
+
+
+def albef_vqa_case(name, case, arrays, meta):
+    torch.manual_seed(0)
+    ref = build_ref_albef_vqa(case)
+    tied = ["text_decoder.cls.predictions.decoder.weight", "text_decoder.cls.predictions.decoder.bias"]
+    listing = [e for e in ec.listing_of(ref.state_dict()) if e[0] not in tied]
+    sd = ec.seeded_state_dict(listing, case["seed"])
+    sd[tied[0]] = sd["text_decoder.bert.embeddings.word_embeddings.weight"]
+    sd[tied[1]] = sd["text_decoder.cls.predictions.bias"]
+    ref.load_state_dict(sd, strict=True)
+    inp = ec.case_inputs(name, case, "albef")
+    answers = ec.answer_list(case)
+    fns = rx.module_items(rx.ALBEF_VQA_MODEL, ["tile"])
+    methods, _ = rx.class_methods(rx.ALBEF_VQA_MODEL, "ALBEF", ["rank_answer"], extra_globals=dict(tile=fns["tile"]))
+    stub = rx.make_stub(methods, text_decoder=_ref_text_decoder(ref), tokenizer=rx.namespace(pad_token_id=0))
+    with torch.no_grad():
+        states = _ref_question_states(ref, inp["image"], inp["ids"], inp["masks"])
+        topk_ids, topk_probs = stub.rank_answer(states, inp["masks"], answers, (answers != 0).long(), case["k_test"])
+        logits = stub.text_decoder(answers[:4], attention_mask=(answers[:4] != 0).long(),
+                                   encoder_hidden_states=states[:1].repeat(4, 1, 1),
+                                   encoder_attention_mask=inp["masks"][:1].repeat(4, 1)).logits
+    arrays[name + "/question_states"] = states.numpy()
+    arrays[name + "/topk_ids"] = topk_ids.numpy()
+    arrays[name + "/topk_probs"] = topk_probs.numpy()
+    arrays[name + "/decoder_logits"] = logits.numpy()
+    meta[name] = dict(flavor="albef_vqa", listing=ec.listing_of(sd), checksums=ec.checksums(sd), seed=case["seed"], tied=tied,
+                      pred=[int(topk_ids[b][int(topk_probs[b].argmax())]) for b in range(2)])
+
+
 def main(npz_path=None, json_path=None):
     npz_path = npz_path or os.path.join(HERE, "encoder_golden.npz")
     json_path = json_path or os.path.join(HERE, "encoder_golden.json")
@@ -306,6 +407,8 @@ def main(npz_path=None, json_path=None):
         vlmo_case(name, case, arrays, meta)
     for name, case in ec.ALBEF_CASES.items():
         albef_case(name, case, arrays, meta)
+    for name, case in ec.ALBEF_VQA_CASES.items():
+        albef_vqa_case(name, case, arrays, meta)
     np.savez_compressed(npz_path, **arrays)
     with open(json_path, "w") as fh:
         json.dump(meta, fh, sort_keys=True)

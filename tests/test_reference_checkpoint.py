@@ -64,9 +64,11 @@ def _state_dict(enc, name):
     rec = meta[name]
     tied = set(rec.get("tied", []))
     sd = ec.seeded_state_dict([e for e in rec["listing"] if e[0] not in tied], rec["seed"])
-    if tied:
-        sd["text_encoder.cls.predictions.decoder.weight"] = sd["text_encoder.bert.embeddings.word_embeddings.weight"]
-        sd["text_encoder.cls.predictions.decoder.bias"] = sd["text_encoder.cls.predictions.bias"]
+    for key in tied:                             # the MLM / LM decoders are tied to their word embeddings and output bias
+        stem = key.split(".cls.")[0]
+        emb = stem + (".bert" if stem + ".bert.embeddings.word_embeddings.weight" in sd else "")
+        sd[key] = sd[emb + ".embeddings.word_embeddings.weight"] if key.endswith("weight") else \
+            sd[stem + ".cls.predictions.bias"]
     for k, want in rec["checksums"].items():
         assert ec.checksum(sd[k]) == want, k
     stored = [k for k in z.files if k.startswith(name + "/sd/")]
@@ -383,3 +385,48 @@ def test_albef_loader_splits_qkv_and_reports(enc):
     bigger = ck.albef_from_reference(sd, image_size=2 * case["image_size"], heads=case["heads"])
     assert bigger.pos_embed.shape[1] == (2 * case["image_size"] // case["patch"]) ** 2 + 1
     assert torch.equal(bigger.pos_embed[:, 0], sd["visual_encoder.pos_embed"][:, 0])
+
+
+# ---- ALBEF VQA victim (black box): fusion encoder + answer decoder + rank_answer ------------------------------------
+def _check_albef_vqa(enc, name, device):
+    """The fine-tuned checkpoint's key layout (``text_encoder.*``, ``text_decoder.bert.*``, ``text_decoder.cls.*``) loaded
+    into the bundled victim: question states, decoder logits and the re-ranked top-k answers equal what the reference's
+    ``BertEncoder`` / ``BertOnlyMLMHead`` classes and its ``rank_answer`` (model_vqa.py:149-203) produce."""
+    z, meta = enc
+    case = ec.ALBEF_VQA_CASES[name]
+    sd = _state_dict(enc, name)
+    model = ck.albef_from_reference({"model": sd}, image_size=case["image_size"], heads=case["heads"], mlm_probability=0.0,
+                                    k_test=case["k_test"]).to(device)
+    assert model.has_vqa and model.cfg.decoder_depth == case["dec_depth"] and model.cfg.fusion_layer == case["fusion_layer"]
+    answers = ec.answer_list(case).to(device)
+    model.set_answer_list(answers)
+    inp = {k: v.to(device) for k, v in ec.case_inputs(name, case, "albef").items()}
+    with torch.no_grad():
+        image_states, _ = model.visual_encoder(inp["image"])
+        states, _ = model.text_encoder(model.text_embeddings(inp["ids"]), inp["masks"], image_states)
+        for b, n in enumerate(case["text_lens"]):                         # padded query rows are not comparable
+            _close(states[b, :n], z[name + "/question_states"][b, :n], FEAT_TOL, name + "/question_states")
+        logits = model._decode(answers[:4], (answers[:4] != 0).long(), states[:1].repeat(4, 1, 1), inp["masks"][:1].repeat(4, 1))
+        real = (answers[:4] != 0).cpu()
+        want = torch.as_tensor(z[name + "/decoder_logits"])
+        err = float((logits.cpu() - want)[real].abs().max()) / float(want[real].abs().max())
+        _note(name + "/decoder_logits", err)
+        assert err <= FEAT_TOL, err
+        topk_ids, topk_probs = model.rank_answer(states, inp["masks"])
+        pred = model.vqa_answer(inp["image"], inp["ids"], inp["masks"])
+    assert pred.cpu().tolist() == meta[name]["pred"]
+    # the reference returns the k candidates re-ranked; same set, same order, same probabilities
+    ref_ids, ref_probs = torch.as_tensor(z[name + "/topk_ids"]), torch.as_tensor(z[name + "/topk_probs"])
+    assert torch.equal(topk_ids.cpu(), ref_ids)
+    assert torch.allclose(topk_probs.cpu(), ref_probs, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(ec.ALBEF_VQA_CASES))
+def test_albef_vqa_victim_reference_state_dict_host(enc, name):
+    _check_albef_vqa(enc, name, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ec.ALBEF_VQA_CASES))
+def test_albef_vqa_victim_reference_state_dict_hip(enc, name):
+    _check_albef_vqa(enc, name, "cuda")

@@ -153,7 +153,7 @@ class FrozenAlbef(nn.Module):
             n_tok = torch.randint(1, cfg.answer_len - 1, (cfg.n_answers,), generator=g)        # 1..answer_len-2 pieces
             ans = torch.zeros(cfg.n_answers, cfg.answer_len, dtype=torch.long)
             ans[:, 0] = cfg.bos_id
-            body = torch.randint(1000, cfg.vocab, (cfg.n_answers, cfg.answer_len), generator=g)
+            body = torch.randint(min(1000, cfg.vocab // 2), cfg.vocab, (cfg.n_answers, cfg.answer_len), generator=g)
             for i in range(cfg.n_answers):
                 ans[i, 1:1 + n_tok[i]] = body[i, :n_tok[i]]
                 ans[i, 1 + n_tok[i]] = cfg.sep_id
