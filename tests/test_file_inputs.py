@@ -326,3 +326,97 @@ def test_entry_run_on_files_equals_the_attack_fed_the_oracles_tensors(tmp_path, 
         a = torch.load(os.path.join(attack_dir, "{}.pt".format(q)))
         b = torch.load(os.path.join(ref_dir, "{}.pt".format(q)))
         assert a.shape == (1, 3, 32, 32) and torch.equal(a, b), q
+
+
+def _entry_vqa(out_path, argv):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "entry"))
+    out = open(out_path, "w")
+    os.dup2(out.fileno(), 1)
+    os.dup2(out.fileno(), 2)
+    sys.argv = ["VQA.py"] + list(argv)
+    import VQA
+    VQA.main()
+    sys.stdout.flush()
+
+
+@pytest.mark.gpu
+def test_entry_vqa_on_files_with_a_reference_format_albef_checkpoint(tmp_path, text_meta):
+    """The ALBEF-flavor entry point (argparse + yaml, ALBEF_attack/VQA.py:119-134) on files: annotation json, images,
+    vocabulary, ``right_part`` filter and a pre-trained checkpoint in the reference's key layout (``visual_encoder.*``,
+    ``text_encoder.bert.*``, ``text_encoder.cls.*``; adv_attack.py:83-92) -> ``attack_dir/<qid>.pt`` + ``adv_txt.json``,
+    identical to the same sweep fed the Pillow oracle's tensors (the white box re-draws its 15 % token mask in every
+    forward, model_pretrain.py:130-132: both runs start from the seed the entry point sets)."""
+    import yaml
+    from oracle import pil_resize
+    from tests.golden import encoder_cases as ec
+    from vqattack_amd.attack.sweep import run_sweep
+    from vqattack_amd.whitebox import checkpoint as ck
+    from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef
+    n = 24
+    arrays = _make_image_set(str(tmp_path / "val2014"), n, seed=9, hw=(96, 128))
+    vocab = _vocab_file(tmp_path, text_meta["vocab"])
+    body = [w for w in text_meta["vocab"][104:] if w.isalpha()]
+    r = np.random.RandomState(2)
+    ann = [{"question_id": 700 + 11 * i, "image": "val2014/img{}.npy".format(i), "dataset": "vqa",
+            "question": " ".join(body[j] for j in r.randint(0, len(body), r.randint(3, 7))) + "?"} for i in range(n)]
+    qfile = str(tmp_path / "vqa_val.json")
+    with open(qfile, "w") as fh:
+        json.dump(ann, fh)
+    keep = [a["question_id"] for a in ann if a["question_id"] % 4]
+    tables_dir = str(tmp_path / "tables")
+    os.makedirs(tables_dir)
+    with open(os.path.join(tables_dir, "right_part.txt"), "w") as fh:
+        fh.write("".join("{}\n".format(q) for q in keep))
+    with open(os.path.join(GOLD, "encoder_golden.json")) as fh:
+        rec = json.load(fh)["albef_tiny"]
+    tied = set(rec["tied"])
+    sd = ec.seeded_state_dict([e for e in rec["listing"] if e[0] not in tied], rec["seed"])
+    ckpt = str(tmp_path / "ALBEF_pretrain.pth")
+    torch.save({"model": sd}, ckpt)
+    cfg_path = str(tmp_path / "VQA.yaml")
+    with open(cfg_path, "w") as fh:
+        yaml.safe_dump(dict(image_res=32, batch_size_test=8, text_len=12, n_samples=0, attack_dir="attack_dir",
+                            vqa_root=str(tmp_path)), fh)
+    out_dir = str(tmp_path / "out")
+    out = str(tmp_path / "vqa.out")
+    argv = ["--config", cfg_path, "--output_dir", out_dir, "--seed", "5", "--mixed", "--questions", qfile, "--vocab_file",
+            vocab, "--tables_dir", tables_dir, "--checkpoint", ckpt]
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=_entry_vqa, args=(out, argv))
+    p.start()
+    p.join(timeout=600)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("entry/VQA.py did not finish within 600 s")
+    text = open(out).read()
+    assert p.exitcode == 0, text[-3000:]
+    adv_txt = json.load(open(os.path.join(out_dir, "adv_txt.json")))
+    assert sorted(map(int, adv_txt)) == sorted(keep)
+    attack_dir = os.path.join(out_dir, "attack_dir")
+    assert sorted(os.listdir(attack_dir)) == sorted("{}.pt".format(q) for q in keep)
+    # the same sweep, fed the oracle's tensors
+    dev = torch.device("cuda", 0)
+    white = ck.albef_from_reference(torch.load(ckpt, weights_only=True), image_size=32, vqa_head=False).to(dev)
+    assert white.cfg.heads == 1                       # the entry point cannot know the head count of a 64-wide test model
+    black = FrozenAlbef.finetuned_from(white, seed=5 + 1).to(dev)
+    src = ds.VqaFilePairs(qfile, str(tmp_path), "albef", 12, 32, tokenizer=WordPiece(vocab),
+                          tables=ds.load_tables(tables_dir, "albef"))
+    by_qid = {a["question_id"]: arrays[i] for i, a in enumerate(ann)}
+
+    def oracle_images(indices, device):
+        rows = [pil_resize.to_tensor_normalize(pil_resize.resize_bicubic_u8(by_qid[src.qids[i]], 32, 32)) for i in indices]
+        return torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(device)
+    src.images, src.prefetch = oracle_images, (lambda indices: None)
+    ref_dir = str(tmp_path / "ref_dir")
+    torch.manual_seed(5)
+    res = run_sweep("albef", white, black, AlbefAttackAdapters(white), 0, 8, 32, 12, dev, mixed=True, save_dir=ref_dir,
+                    log_every=0, source=src)
+    assert res["adv_text"] == adv_txt
+    for q in keep:
+        a = torch.load(os.path.join(attack_dir, "{}.pt".format(q)))
+        b = torch.load(os.path.join(ref_dir, "{}.pt".format(q)))
+        assert torch.equal(a, b), q
