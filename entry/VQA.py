@@ -37,12 +37,15 @@ def main():
     ap.add_argument("--tables_dir", default="", help="directory of the reference's in-tree *.txt tables")
     ap.add_argument("--checkpoint", default="", help="pre-trained ALBEF checkpoint -> white box (adv_attack.py:83)")
     ap.add_argument("--checkpoint_vqa", default="", help="VQA fine-tuned checkpoint -> victim (adv_attack.py:96)")
+    ap.add_argument("--sim_threshold", default=0.95, type=float,
+                    help="sentence-similarity floor of a substitution (adv_attack.py:303)")
     ap.add_argument("--mlm_checkpoint", default="", help="BertForMaskedLM state dict -> candidate proposer (adv_attack.py:110)")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
     rank, world, device = init_distributed()
     seed_everything(args.seed, rank)
 
+    from vqattack_amd.attack.runner import AttackConfig
     from vqattack_amd.attack.sweep import run_sweep
     from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef, albef_base, albef_tiny
     from vqattack_amd.whitebox import checkpoint
@@ -70,7 +73,8 @@ def main():
                     cfg["batch_size_test"], mcfg.image_size, text_len, device,
                     rank, world, joint=not args.image_only, save_dir=out_dir, seed=args.seed,
                     max_words=4 if args.tiny else 12, dual_every=args.dual_every, mixed=args.mixed,
-                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned)
+                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned,
+                    config=AttackConfig(sim_threshold=args.sim_threshold))
     finish(rank, world, res, os.path.join(args.output_dir, "adv_txt.json") if args.output_dir else None)
 
 

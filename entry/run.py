@@ -30,7 +30,7 @@ NAMED = {
 }
 DEFAULTS = dict(arch="vlmo_base", image_size=384, max_text_len=40, per_gpu_batchsize=64, seed=1, test_only=True,
                 n_samples=128, image_only=False, attack_dir="", dual_every=0, mixed=False, questions="", image_root="",
-                vocab_file="", tables_dir="", pretrain_path="", load_path="", mlm_checkpoint="")
+                vocab_file="", tables_dir="", pretrain_path="", load_path="", mlm_checkpoint="", sim_threshold=0.95)
 
 
 def parse(argv):
@@ -57,6 +57,7 @@ def main():
         raise SystemExit("only the attack (test_only=True) is implemented; training is out of scope")
     rank, world, device = init_distributed()
     seed_everything(cfg["seed"], rank)
+    from vqattack_amd.attack.runner import AttackConfig
     from vqattack_amd.attack.sweep import run_sweep
     from vqattack_amd.whitebox import vlmo
     from vqattack_amd.whitebox import checkpoint
@@ -84,7 +85,8 @@ def main():
                     mcfg.image_size, mcfg.max_text_len, device, rank, world, joint=not cfg["image_only"],
                     save_dir=cfg["attack_dir"] or None, seed=cfg["seed"],
                     max_words=4 if cfg["arch"] == "vlmo_tiny" else 12, dual_every=cfg["dual_every"], mixed=cfg["mixed"],
-                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned)
+                    force_collective=dist.is_initialized(), source=source, mlm_logits_fn=proposer, banned_ids=banned,
+                    config=AttackConfig(sim_threshold=cfg["sim_threshold"]))      # adv_attack.py:303: 0.95
     # adversarial images <qid>.pt and the adversarial-text json go to attack_dir (vlmo_module.py:166-167,2059-2062,2095-2097)
     finish(rank, world, res, os.path.join(cfg["attack_dir"], "adv_txt.json") if cfg["attack_dir"] else None)
 

@@ -282,7 +282,7 @@ def test_entry_run_on_files_equals_the_attack_fed_the_oracles_tensors(tmp_path, 
     out = str(tmp_path / "run.out")
     argv = ["with", "image_size=32", "max_text_len=40", "per_gpu_batchsize=16", "mixed=True", "questions=" + qfile,
             "image_root=" + str(tmp_path), "vocab_file=" + vocab, "tables_dir=" + tables_dir, "pretrain_path=" + ckpt,
-            "mlm_checkpoint=" + mlm_ckpt, "attack_dir=" + attack_dir, "seed=3"]
+            "mlm_checkpoint=" + mlm_ckpt, "attack_dir=" + attack_dir, "seed=3", "sim_threshold=0.2"]
     ctx = multiprocessing.get_context("forkserver")
     p = ctx.Process(target=_entry_run, args=(out, argv))
     p.start()
@@ -317,7 +317,8 @@ def test_entry_run_on_files_equals_the_attack_fed_the_oracles_tensors(tmp_path, 
     proposer = BertMlmProposer.from_hf_state_dict(torch.load(mlm_ckpt, weights_only=True)).to(dev)
     banned = banned_ids(WordPiece(vocab).tokens, ds.DEFAULT_STOP_WORDS).to(dev)
     res = run_sweep("vlmo", white, black, VlmoAttackAdapters(white), 0, 16, 32, 40, dev, mixed=True, save_dir=ref_dir,
-                    log_every=0, source=src, config=AttackConfig(), mlm_logits_fn=proposer, banned_ids=banned)
+                    log_every=0, source=src, config=AttackConfig(sim_threshold=0.2), mlm_logits_fn=proposer,
+                    banned_ids=banned)
     assert any(row != src.ids[i].tolist() for i, row in enumerate(res["adv_text"][str(q)] for q in src.qids)), \
         "the proposer's candidates never led to a substitution: the text side of the test would be vacuous"
     assert res["n_total"] == len(keep) and res["skipped"] == n - len(keep)
@@ -356,7 +357,7 @@ def test_entry_vqa_on_files_with_a_reference_format_albef_checkpoint(tmp_path, t
     from vqattack_amd.whitebox import checkpoint as ck
     from vqattack_amd.whitebox.albef import AlbefAttackAdapters, FrozenAlbef
     n = 24
-    arrays = _make_image_set(str(tmp_path / "val2014"), n, seed=9, hw=(96, 128))
+    arrays = _make_image_set(str(tmp_path / "val2014"), n, seed=9, hw=(240, 320))
     vocab = _vocab_file(tmp_path, text_meta["vocab"])
     body = [w for w in text_meta["vocab"][104:] if w.isalpha()]
     r = np.random.RandomState(2)
@@ -383,7 +384,7 @@ def test_entry_vqa_on_files_with_a_reference_format_albef_checkpoint(tmp_path, t
     out_dir = str(tmp_path / "out")
     out = str(tmp_path / "vqa.out")
     argv = ["--config", cfg_path, "--output_dir", out_dir, "--seed", "5", "--mixed", "--questions", qfile, "--vocab_file",
-            vocab, "--tables_dir", tables_dir, "--checkpoint", ckpt]
+            vocab, "--tables_dir", tables_dir, "--checkpoint", ckpt, "--sim_threshold", "0.2"]
     ctx = multiprocessing.get_context("forkserver")
     p = ctx.Process(target=_entry_vqa, args=(out, argv))
     p.start()
@@ -413,8 +414,9 @@ def test_entry_vqa_on_files_with_a_reference_format_albef_checkpoint(tmp_path, t
     src.images, src.prefetch = oracle_images, (lambda indices: None)
     ref_dir = str(tmp_path / "ref_dir")
     torch.manual_seed(5)
+    from vqattack_amd.attack.runner import AttackConfig
     res = run_sweep("albef", white, black, AlbefAttackAdapters(white), 0, 8, 32, 12, dev, mixed=True, save_dir=ref_dir,
-                    log_every=0, source=src)
+                    log_every=0, source=src, config=AttackConfig(sim_threshold=0.2))
     assert res["adv_text"] == adv_txt
     for q in keep:
         a = torch.load(os.path.join(attack_dir, "{}.pt".format(q)))
