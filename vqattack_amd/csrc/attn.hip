@@ -105,18 +105,23 @@ struct SplitArgs {
 __host__ __device__ __forceinline__ long split_fwd_floats(long rows_q, int n) { return rows_q * n * 66; }
 __host__ __device__ __forceinline__ long split_sum_floats(long rows, int n) { return rows * n * 64; }
 
-// (b, h, s) row of 64 floats per 16 lanes: out = sum over parts, in part order.
-__global__ __launch_bounds__(kBlock) void attn_sum_parts_kernel(const float* __restrict__ ws, int n, long rows,
-                                                                float* __restrict__ out, int H, int S, long sb, long ss,
-                                                                long sh) {
+// (b, h, s) row of 64 floats per 16 lanes: out = sum over parts, in part order.  blockIdx.y selects one of up to two
+// (workspace, output) pairs of the same row count -- dk and dv are reduced by ONE launch.
+struct SumTarget {
+  const float* ws;
+  float* out;
+  long sb, ss, sh;
+};
+__global__ __launch_bounds__(kBlock) void attn_sum_parts_kernel(SumTarget t0, SumTarget t1, int n, long rows, int H, int S) {
   const long row = static_cast<long>(blockIdx.x) * (kBlock / 16) + threadIdx.x / 16;
   if (row >= rows) return;
+  const SumTarget t = blockIdx.y == 0 ? t0 : t1;
   const int c4 = (threadIdx.x & 15) * 4;
-  f32x4 acc = *reinterpret_cast<const f32x4*>(ws + row * 64 + c4);
-  for (int p = 1; p < n; ++p) acc += *reinterpret_cast<const f32x4*>(ws + (p * rows + row) * 64 + c4);
+  f32x4 acc = *reinterpret_cast<const f32x4*>(t.ws + row * 64 + c4);
+  for (int p = 1; p < n; ++p) acc += *reinterpret_cast<const f32x4*>(t.ws + (p * rows + row) * 64 + c4);
   const int s = static_cast<int>(row % S), head = static_cast<int>((row / S) % H);
   const long b = row / (static_cast<long>(S) * H);
-  *reinterpret_cast<f32x4*>(out + b * sb + head * sh + static_cast<long>(s) * ss + c4) = acc;
+  *reinterpret_cast<f32x4*>(t.out + b * t.sb + head * t.sh + static_cast<long>(s) * t.ss + c4) = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -1077,12 +1082,12 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
       attn_bwd_dkv_kernel<false, true, true, true><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
                                                                           g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
                                                                           ds_ws, scores, sp);
-    const dim3 gsk(static_cast<unsigned>((rk + per - 1) / per)), gsq(static_cast<unsigned>((rq + per - 1) / per));
-    attn_sum_parts_kernel<<<gsk, kBlock, 0, st>>>(split_ws, nsplit, rk, dk, H, Sk, g[6], g[7], g[8]);
-    attn_sum_parts_kernel<<<gsk, kBlock, 0, st>>>(split_ws + split_sum_floats(rk, nsplit), nsplit, rk, dv, H, Sk, g[9],
-                                                  g[10], g[11]);
+    const dim3 gsk(static_cast<unsigned>((rk + per - 1) / per), 2), gsq(static_cast<unsigned>((rq + per - 1) / per), 1);
+    const SumTarget tk{split_ws, dk, g[6], g[7], g[8]}, tv{split_ws + split_sum_floats(rk, nsplit), dv, g[9], g[10], g[11]};
+    attn_sum_parts_kernel<<<gsk, kBlock, 0, st>>>(tk, tv, nsplit, rk, H, Sk);                       // dk and dv in one launch
     attn_bwd_dq_staged_kernel<true><<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5], sp);   // after the sums: same ws
-    attn_sum_parts_kernel<<<gsq, kBlock, 0, st>>>(split_ws, nsplit, rq, dq, H, Sq, g[3], g[4], g[5]);
+    const SumTarget tq{split_ws, dq, g[3], g[4], g[5]};
+    attn_sum_parts_kernel<<<gsq, kBlock, 0, st>>>(tq, tq, nsplit, rq, H, Sq);
     return launch_status();
   }
   if (ds_ws) {                                   // 5 products: delta pre-pass, dK / dV (+ dS^T store), dQ from dS^T
