@@ -27,7 +27,8 @@ def _sdpa(q, k, v, bias, scale=None):
 
 
 @pytest.mark.parametrize("b,h,sq,sk,packed", [(2, 3, 77, 77, False), (1, 2, 587, 587, True), (2, 1, 33, 160, False),
-                                               (3, 4, 128, 128, True), (1, 1, 1, 5, False), (1, 12, 617, 617, True)])
+                                               (3, 4, 128, 128, True), (1, 1, 1, 5, False), (1, 12, 617, 617, True),
+                                               (1, 12, 25, 577, False)])     # ALBEF's cross-attention at batch 1
 @pytest.mark.parametrize("bias_kind", ["none", "shared", "per_batch_padding"])
 def test_attention_forward_matches_sdpa(b, h, sq, sk, packed, bias_kind):
     from vqattack_amd import attention
@@ -53,7 +54,8 @@ def test_attention_forward_matches_sdpa(b, h, sq, sk, packed, bias_kind):
     assert torch.allclose(lse, torch.logsumexp(scores, dim=-1), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("b,h,sq,sk", [(2, 3, 77, 77), (1, 2, 587, 587), (2, 1, 33, 160), (3, 4, 128, 128), (1, 1, 1, 5)])
+@pytest.mark.parametrize("b,h,sq,sk", [(2, 3, 77, 77), (1, 2, 587, 587), (2, 1, 33, 160), (3, 4, 128, 128), (1, 1, 1, 5),
+                                       (1, 12, 25, 577)])
 @pytest.mark.parametrize("bias_kind", ["none", "shared", "per_batch_padding"])
 @pytest.mark.parametrize("form", ["saved_scores", "ds_workspace", "recompute"])
 def test_attention_backward_matches_sdpa(b, h, sq, sk, bias_kind, form, monkeypatch):
@@ -248,6 +250,8 @@ def test_loop_split_heuristic_and_abi_validation(monkeypatch):
     n1 = attention.loop_split(1, 12, 591, 591, DEV)                          # the reference's own batch 1 does not
     assert 2 <= n1 <= 8 and 12 * 5 * n1 <= 2 * cus + 12 * 5
     assert attention.loop_split(1, 1, 20, 20, DEV) == 1                      # one tile: nothing to cut
+    assert attention.loop_split(1, 12, 25, 577, DEV) == 1                    # cross-attention, backward: one query tile
+    assert attention.loop_split(1, 12, 25, 577, DEV, backward=False) >= 4    # ... its forward loops over 19 key tiles
     lib = _hip.lib()
     assert lib.vqa_attn_split_ws_floats(1, 12, 591, 591, 1) == 0
     assert lib.vqa_attn_split_ws_floats(1, 12, 591, 591, 4) == max(12 * 591 * 4 * 66, 2 * 12 * 591 * 4 * 64)

@@ -111,14 +111,16 @@ def _split_hole(bias):
 _CUS = {}
 
 
-def loop_split(b, h, sq, sk, device):
+def loop_split(b, h, sq, sk, device, backward=True):
     """Parts the kernels' tile loops are cut into for this shape (1 = not at all).  A launch has
     ``b * h * ceil(s / 128)`` workgroups, each a serial chain over ``ceil(s / 32)`` tiles: with fewer workgroups than the
     chip can hold (2 per CU) -- the reference's own batch 1: 60 on 256 CUs -- the loop is cut so that about that many
-    run, at most 8 parts and never fewer than 2 tiles per part.  ``VQA_ATTN_SPLIT=n`` pins it (experiments)."""
+    run, at most 8 parts and never fewer than 2 tiles per part.  The forward loops over KEY tiles; the backward's two
+    kernels loop over query tiles (dK / dV) and key tiles (dQ), so its count is bounded by the shorter side (ALBEF's
+    cross-attention: 25 text queries on 577 image keys splits forward only).  ``VQA_ATTN_SPLIT=n`` pins it (experiments)."""
     import os
     pinned = os.environ.get("VQA_ATTN_SPLIT")
-    tiles = (min(sq, sk) + 31) // 32
+    tiles = ((min(sq, sk) if backward else sk) + 31) // 32
     if pinned:
         return max(1, min(int(pinned), tiles))
     dev = torch.device(device).index or 0
@@ -142,7 +144,7 @@ def _forward(q, k, v, bias, bstr, scale, save_scores=False, key_hole=None):
     ``key_hole``: int32 (B, 2) device tensor, see ``KeyHoleBias``."""
     b, sq, h, _ = q.shape
     sk = k.shape[1]
-    nsplit = loop_split(b, h, sq, sk, q.device)
+    nsplit = loop_split(b, h, sq, sk, q.device, backward=False)
     sws = _split_ws(b, h, sq, sk, nsplit, q.device)
     o = torch.empty((b, sq, h, HEAD_DIM), dtype=torch.float32, device=q.device)
     lse = torch.empty((b, h, sq), dtype=torch.float32, device=q.device)
