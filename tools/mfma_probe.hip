@@ -105,9 +105,78 @@ __global__ __launch_bounds__(kBlock, 2) void attn_like(float* out, float seed) {
   if (acc == 123.456f) out[0] = acc;
 }
 
+// MODE 8 / 9 (round 6): the same work as mode 6, SOFTWARE-PIPELINED across tiles -- the S^T chain of tile t + 1 is
+// independent of the softmax of tile t, so its 32 MFMAs can be issued with tile t's vector block in their shadow (each
+// dependent MFMA waits ~64 cycles for its predecessor; does the wave issue independent VALU work meanwhile, or does vector
+// issue serialise with the matrix pipe as modes 6 / 7 suggested?).  8: source order S-chain, softmax, PV -- the compiler
+// schedules; 9: the interleaving forced with sched_group_barrier (1 MFMA : 3 VALU).  Two accumulator sets ping-pong (no
+// register copies).
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 2) void attn_pipe(float* out, float seed) {
+  __shared__ float Ks[32 * 65];
+  __shared__ float Vs[32 * 72];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < 32 * 65; i += kBlock) Ks[i] = seed * static_cast<float>(i & 7);
+  for (int i = threadIdx.x; i < 32 * 72; i += kBlock) Vs[i] = seed * static_cast<float>(i & 3);
+  __syncthreads();
+  f32x16 o0 = {0}, o1 = {0};
+  float qf[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qf[s] = seed * static_cast<float>(s + lane);
+  float m = 0.0f, l = 0.0f;
+  auto tile = [&](f32x16& cur, f32x16& nxt) {
+    nxt = f32x16{0};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[r * 65 + s + 32 * h], qf[s], nxt, 0, 0, 0);
+    float mx = cur[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, cur[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __expf(m - m_new);
+    float rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      cur[i] = __expf(cur[i] - m_new);
+      rs += cur[i];
+    }
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o0[i] *= alpha;
+      o1[i] *= alpha;
+    }
+    if (MODE == 9) {
+#pragma unroll
+      for (int g = 0; g < 32; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);       // three VALU instructions in its shadow
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 72 + r], cur[i], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 72 + 32 + r], cur[i], o1, 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  f32x16 sa = {0}, sb = {0};
+  for (int it = 0; it < kIters; it += 2) {
+    tile(sa, sb);
+    tile(sb, sa);
+  }
+  float acc = l;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += o0[i] + o1[i] + sa[i];
+  if (acc == 123.456f) out[0] = acc;
+}
+
 template <int MODE>
 static void launch(int grid, float* out) {
-  if (MODE >= 5) attn_like<MODE><<<grid, kBlock>>>(out, 0.0f);
+  if (MODE >= 8) attn_pipe<MODE><<<grid, kBlock>>>(out, 0.0f);
+  else if (MODE >= 5) attn_like<MODE><<<grid, kBlock>>>(out, 0.0f);
   else probe<(MODE < 5 ? MODE : 0)><<<grid, kBlock>>>(out, 0.0f);
 }
 
@@ -149,6 +218,8 @@ int main() {
       run<5>(w, p.multiProcessorCount, mhz, out);
       run<6>(w, p.multiProcessorCount, mhz, out);
       run<7>(w, p.multiProcessorCount, mhz, out);
+      run<8>(w, p.multiProcessorCount, mhz, out);
+      run<9>(w, p.multiProcessorCount, mhz, out);
     }
   }
   return 0;
