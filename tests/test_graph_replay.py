@@ -32,6 +32,38 @@ def test_graphed_pgd_equals_eager(batch):
                                                 clip_min=-1, clip_max=1, ori_x=x0, time=1, ls=1, flavor="vlmo")
 
 
+def test_environment_opt_in_replays_eligible_calls_only(monkeypatch):
+    """``VQA_PGD_GRAPH=1``: an unmodified driver's L-inf feature-loss call is replayed (same bits as eager), its L2 call
+    is left alone instead of raising."""
+    import vqattack_amd
+    from vqattack_amd import attacks
+    from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny
+    cfg = vlmo_tiny()
+    model = FrozenVlmo(cfg, seed=5).to(DEV)
+    ad = VlmoAttackAdapters(model)
+    ids = torch.tensor([[101, 2054, 3609, 2003, 102, 0, 0, 0]], device=DEV)
+    ad.set_text(ids, (ids != 0).long())
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.empty(1, 3, cfg.image_size, cfg.image_size).uniform_(-1, 1, generator=g).to(DEV)
+    eta = torch.empty(x0.shape).uniform_(-0.125, 0.125, generator=g).to(DEV)
+    y = ad.gen_ori_feats(x0)
+    kw = dict(clip_min=-1, clip_max=1, ori_x=x0, time=0, ls=1, flavor="vlmo", init_eta=eta)
+    calls = []
+    real = attacks._graphed_linf_loop
+    monkeypatch.setattr(attacks, "_graphed_linf_loop", lambda *a, **k: calls.append(1) or real(*a, **k))
+    with torch.enable_grad():
+        adv_e, loss_e = vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, 5, np.inf, y=list(y), **kw)
+        assert not calls
+        monkeypatch.setenv("VQA_PGD_GRAPH", "1")
+        adv_g, loss_g = vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, 5, np.inf, y=list(y), **kw)
+        assert calls == [1]
+        vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 0.125, 0.01, 5, np.inf, y=list(y), graph=False, **kw)
+        vqattack_amd.projected_gradient_descent(ad.pgd_attack, x0, 2.0, 0.5, 2, 2, y=list(y), clip_min=-1, clip_max=1,
+                                                ori_x=x0, time=1, ls=1, flavor="vlmo")
+        assert calls == [1]
+    assert torch.equal(adv_e, adv_g) and loss_e == loss_g
+
+
 def test_runner_with_graph_replay_equals_eager():
     from vqattack_amd.attack.runner import AttackConfig, BatchedVQAttack
     from vqattack_amd.whitebox.vlmo import FrozenVlmo, VlmoAttackAdapters, vlmo_tiny

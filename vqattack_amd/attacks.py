@@ -20,6 +20,8 @@ What is different underneath (and invisible to a caller):
     two ping-pong image buffers.
 There is no CPU path: CPU tensors raise ``HipExtensionError``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -457,7 +459,7 @@ def _graphed_linf_loop(model_fn, cur, x0, y, flavor, targeted, eps_iter, eps, cl
 
 def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_min=None, clip_max=None, y=None,
                                ori_x=None, time=None, targeted=False, rand_init=True, rand_minmax=None,
-                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None, graph=False,
+                               sanity_checks=True, ls=None, *, flavor=ALBEF, init_eta=None, graph=None,
                                per_sample=False):
     """PGD over a frozen white box; returns ``(adv_x, loss_list)``, bare ``x`` when eps or eps_iter is 0.
 
@@ -468,7 +470,11 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     normalised per sample (every sample's gradient then equals the batch-1 reference's; the reported loss is the sum
     of the per-sample losses instead of ``F.cross_entropy``'s batch mean).
     ``graph`` (extension, keyword-only): capture one iteration into a hipGraph and replay it (``ls == 1``, L-inf,
-    two-sided or no clipping; for small, launch-bound batches -- see ``_graphed_linf_loop``).
+    two-sided or no clipping; for small, launch-bound batches -- see ``_graphed_linf_loop``).  Unmodified drivers
+    that cannot pass the keyword opt in with ``VQA_PGD_GRAPH=1`` in the environment: eligible calls that leave ``graph``
+    unset are then replayed,
+    every other call (dual loss, L1 / L2, one-sided clipping) runs eagerly as before.  The closure must be capturable
+    (no host read such as ``.item()`` inside it).
     Reference: A projected_gradient_descent.py:10-199, V :10-196.
     """
     _check_flavor(flavor)
@@ -491,6 +497,8 @@ def projected_gradient_descent(model_fn, x, eps, eps_iter, nb_iter, norm, clip_m
     ws = ops.Workspace()       # loss-gradient / CE scratch buffers live for the whole call, not per iteration
     bad_flag = flag if flag is not None else (
         ops.new_flag(xin.device) if ((dual and sanity_checks) or norm != np.inf) else None)
+    if graph is None and os.environ.get("VQA_PGD_GRAPH") == "1":
+        graph = not dual and norm == np.inf and (clip_min is None) == (clip_max is None)
     if graph and nb_iter > 0:
         if dual or norm != np.inf:
             raise ValueError("graph=True supports the feature-loss (ls == 1) L-inf loop only")
