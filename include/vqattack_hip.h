@@ -280,7 +280,9 @@ int vqa_greedy_accept(const int32_t* cand, const int32_t* order, const int32_t* 
  * is masked, never used).  lse (B, H, Sq) receives log-sum-exp of the scores.
  * scores (nullable; vqa_attn_scores_floats(B, H, Sq, Sk) floats, 16-byte aligned): when given, the forward also stores
  * the pre-softmax scores scale * q k^T + bias -- a forward that will be differentiated hands them to vqa_attn_bwd, whose
- * key-block kernel then skips the q k^T product and the bias.
+ * key-block kernel then skips the q k^T product and the bias.  The buffer is OPAQUE: per (batch, head) a grid of 32 x 32
+ * tiles over ceil128(Sq) x ceil128(Sk), each tile in the register order of the wave that produced it (csrc/attn.hip);
+ * only vqa_attn_bwd of the same B, H, Sq, Sk reads it.
  * key_hole (nullable, int32 (B, 2)): keys [key_hole[2b], key_hole[2b+1]) of batch element b score -inf for every head
  * and query -- the padded text tokens of a question shorter than the batch's text length (key padding of the reference's
  * attention mask).  It lets a ragged batch share ONE (1, H, S, S) relative-position slab (batch stride 0) instead of a
@@ -302,7 +304,8 @@ long vqa_attn_split_ws_floats(int B, int H, int Sq, int Sk, int nsplit);
  * float atomics: bitwise reproducible), two forms:
  *   ds_ws != NULL (vqa_attn_bwd_ws_floats(B, H, Sq, Sk) floats, 16-byte aligned, contents irrelevant): 5 products.  A
  *     streaming pre-pass writes delta (B, H, Sq) = rowsum(go . o); the kernel that owns key blocks computes dk, dv and
- *     stores the dS tiles it forms on the way, transposed, into ds_ws; a third kernel forms dq from them.  With
+ *     stores the dS tiles it forms on the way, transposed, into ds_ws (tiled like `scores`); a third kernel forms dq
+ *     from them.  With
  *     scores != NULL (what vqa_attn_fwd stored for the same operands) the key-block kernel reads the scores instead of
  *     recomputing them: 4 products.
  *   ds_ws == NULL: 7 products, no workspace: one kernel owns query blocks (dq; it also writes delta), one owns key

@@ -68,12 +68,7 @@ def main():
         forms = [("hip bwd kernels, from saved scores", dict(scores=scores), None),
                  ("hip bwd kernels, dS workspace only", dict(), None),
                  ("hip bwd kernels, recompute form", dict(workspace=False), None)]
-        if _hip.set_option(9, 1):        # tuning build (VQA_TUNING_LIB=1): A/B of the dQ-from-dS^T kernel, alternating
-            forms = [("hip bwd kernels, from saved scores, dQ kernel with direct dword loads (round 3)", dict(scores=scores), 0),
-                     ("hip bwd kernels, from saved scores, dQ kernel staged through LDS", dict(scores=scores), 1)] * 3 + forms[1:]
         for what, kw, knob in forms:
-            if knob is not None:
-                _hip.set_option(9, knob)
             ms = timeit(lambda: attention._backward(q, k, v, bias, bstr, o, lse, go, dqkv[:, :, 0], dqkv[:, :, 1],
                                                     dqkv[:, :, 2], D ** -0.5, **kw))
             print(json.dumps(dict(what=what, ms=round(ms, 3), TFLOPs=round(2.5 * flops_fwd / ms / 1e9, 1))),

@@ -27,7 +27,10 @@ for k, c in agg.items():
     if "SQ_WAVE_CYCLES" in m:
         w = m["SQ_WAVE_CYCLES"]
         out.append("waves/SIMD %.2f" % (w * 4 / 1024 / cyc))
-        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
+                  "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"):
             if n in m:
                 out.append("%s %.3f" % (n[3:].lower(), m[n] / w))
+    if "SQ_LDS_BANK_CONFLICT" in m:
+        out.append("lds bank-conflict cycles / SE-busy %.3f" % (m["SQ_LDS_BANK_CONFLICT"] / 256 / cyc))      # per CU
     print("  ".join(out))

@@ -36,6 +36,49 @@ struct AttnDims {
   float scale;
 };
 
+// Tuning build only (tools/attn_stamps.py): where a tile of the loop spends its cycles.  s_memtime stamps bracket the
+// segments of a tile; each wave adds its segment sums to d_attn_stamps[kernel * 10 + segment] (+ its tile count in slot
+// 9) after the loop.  No stamp exists in the shipped library; a stamped build's run time is not a measurement (the
+// fences forbid overlaps the real kernel has) -- its SHARES are.
+#ifdef VQA_TUNING
+__device__ int d_attn_ablate = 0;        // tuning build only, timing ablations (results are wrong): 1 = no score / dS stores
+#define VQA_ABLATE(bit) (d_attn_ablate & (bit))
+__device__ unsigned long long* d_attn_stamps = nullptr;
+#define VQA_STAMP_DECL unsigned long long stamp_t = 0, stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const bool stamp_on = d_attn_stamps != nullptr;
+#define VQA_STAMP_START()                                                                              \
+  do {                                                                                                 \
+    if (stamp_on) {                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t)::"memory");                  \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
+  } while (0)
+#define VQA_STAMP(seg)                                                                                 \
+  do {                                                                                                 \
+    if (stamp_on) {                                                                                    \
+      unsigned long long stamp_now;                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_now)::"memory");                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      stamp_sum[seg] += stamp_now - stamp_t;                                                           \
+      stamp_t = stamp_now;                                                                             \
+    }                                                                                                  \
+  } while (0)
+#define VQA_STAMP_FLUSH(kernel, tiles)                                                                 \
+  do {                                                                                                 \
+    if (stamp_on && (threadIdx.x & (kWave - 1)) == 0) {                                                \
+      for (int i = 0; i < 8; ++i) atomicAdd(d_attn_stamps + (kernel) * 10 + i, stamp_sum[i]);          \
+      atomicAdd(d_attn_stamps + (kernel) * 10 + 9, static_cast<unsigned long long>(tiles));            \
+    }                                                                                                  \
+  } while (0)
+#else
+#define VQA_ABLATE(bit) false
+#define VQA_STAMP_DECL
+#define VQA_STAMP_START() do {} while (0)
+#define VQA_STAMP(seg) do {} while (0)
+#define VQA_STAMP_FLUSH(kernel, tiles) do {} while (0)
+#endif
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -138,13 +181,22 @@ __global__ __launch_bounds__(kBlock) void attn_sum_parts_kernel(SumTarget t0, Su
 //   * keys beyond Sk are masked in the last tile only; tile rows beyond the sequence are clamped, not zero-filled;
 //   * V sits in LDS with dimensions d and d + 32 interleaved, so one ds_read_b64 with an immediate offset feeds both
 //     P.V products of a key and no address arithmetic is left in the loop.
-// Row counts / pitches of the two optional workspaces: scores (B, H, ceil128(Sq), ceil32(Sk)) written by the forward
-// and dS^T (B, H, ceil128(Sk), ceil32(Sq)) written by the dK / dV kernel.  Rows go up to the workgroup's 128 so that
-// every lane of a live wave owns one; pitches are whole 32-wide tiles.
+// The two optional workspaces -- scores (B, H, ceil128(Sq), ceil128(Sk)) written by the forward and dS^T
+// (B, H, ceil128(Sk), ceil128(Sq)) written by the dK / dV kernel -- are BLOCKED: a (batch, head) slab is a grid of
+// 32 x 32 tiles, [tile row][tile column][1024 floats], and a tile holds the producing wave's accumulator image as it
+// sits in registers: the 16-byte chunk g (of 4) of lane l at float 256 g + 4 l.  A store instruction of the producer
+// then writes 1 KB of consecutive bytes (8 cache lines) instead of 16-byte pieces of 32 lines, and the consumer -- which
+// stages a 32 x 128 block through LDS anyway -- fetches 16 KB of consecutive bytes and puts every chunk where the
+// row-major tile image wants it (chunk g of lane (r, h) = row r, columns 8 g + 4 h .. + 3 of its tile).  With the
+// row-major form, taking the stores out of the two kernels (results wrong, timing only) saved 12 % of the forward and
+// 10 % of the backward at the bench shape: the request rate of the scattered pieces, not their bytes.
+// Both grids are padded to whole 128-row / 128-column groups, so every block a consumer touches exists; blocks no
+// producer wave wrote are only read into lanes whose results are discarded.
 __host__ __device__ __forceinline__ long sc_rows(int Sq) { return (Sq + 127L) / 128 * 128; }
-__host__ __device__ __forceinline__ long sc_pitch(int Sk) { return (Sk + 31L) / 32 * 32; }
+__host__ __device__ __forceinline__ long sc_pitch(int Sk) { return (Sk + 127L) / 128 * 128; }
 __host__ __device__ __forceinline__ long ds_rows(int Sk) { return (Sk + 127L) / 128 * 128; }
-__host__ __device__ __forceinline__ long ds_pitch(int Sq) { return (Sq + 31L) / 32 * 32; }
+__host__ __device__ __forceinline__ long ds_pitch(int Sq) { return (Sq + 127L) / 128 * 128; }
+constexpr int kBlockFloats = kTile * kTile;      // one 32 x 32 tile of a blocked workspace
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -172,16 +224,37 @@ __device__ __forceinline__ float halves_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// 32 x 64 tile -> registers, rows clamped to the last valid one (their products are masked or multiplied by P = 0).
-__device__ __forceinline__ TileRegs load_tile_clamped(const float* __restrict__ base, long ss, int row0, int n_rows) {
+// 32 x 64 tiles of a (rows, 64) operand -> registers, one tile after another; thread t fetches 32 bytes of row t / 8.
+// Rows beyond the sequence are clamped to the last valid one (their products are masked or multiplied by P = 0), which
+// only the LAST tile can need: the cursor keeps the thread's clamped address in that tile, computed once, and a plain
+// pointer that moves by one tile per load -- a tile costs one 64-bit add and a select per operand.  (The form it
+// replaces clamped the row and rebuilt the address per tile: a min, three 32-bit multiplies and a 64-bit multiply-add
+// per operand, quarter-rate instructions, and vector instructions are paid in matrix-pipe time on this chip -- see the
+// forward's notes; tools/isa_loop_mix.py lists what a loop is left with.)
+struct TileCursor {
+  const float* p;       // this thread's 32 bytes of the tile the cursor is at
+  const float* last;    // the same of the sequence's last tile, row clamped
+  long step;            // floats per tile (uniform)
+  int last_tile;
+};
+__device__ __forceinline__ TileCursor tile_cursor(const float* __restrict__ base, long ss, int n_rows, int tile) {
+  const int lrow = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+  TileCursor c;
+  c.last_tile = (n_rows - 1) / kTile;
+  int row = c.last_tile * kTile + lrow;
+  row = row < n_rows ? row : n_rows - 1;
+  c.last = base + static_cast<long>(row) * ss + c8;
+  c.p = base + (static_cast<long>(tile) * kTile + lrow) * ss + c8;
+  c.step = kTile * ss;
+  return c;
+}
+// loads tile `tile` -- the one the cursor is at -- and moves the cursor to the next
+__device__ __forceinline__ TileRegs load_tile_next(TileCursor& c, int tile) {
+  const float* p = tile == c.last_tile ? c.last : c.p;
   TileRegs t;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int idx = threadIdx.x * 2 + j;
-    int row = row0 + (idx >> 4);
-    row = row < n_rows ? row : n_rows - 1;
-    t.v[j] = *reinterpret_cast<const f32x4*>(base + static_cast<long>(row) * ss + (idx & 15) * 4);
-  }
+  t.v[0] = *reinterpret_cast<const f32x4*>(p);
+  t.v[1] = *reinterpret_cast<const f32x4*>(p + 4);
+  c.p += c.step;
   return t;
 }
 
@@ -234,8 +307,9 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   const float* vb = v + b * d.v_sb + head * d.v_sh;
   const float* bp = HAS_BIAS ? bias + b * d.bias_sb + head * d.bias_sh + static_cast<long>(ql) * d.bias_sr + 4 * h
                              : nullptr;
-  // scores[(batch, head)][query][key], pitches ceil128(Sq) x ceil32(Sk): this lane's row, at its half's key offset
-  float* scp = STORE_S ? scores + ((static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) + qi) * sc_pitch(d.Sk) + 4 * h
+  // scores: this wave's row of tiles (query tile q0 / 32) in the blocked slab, at this lane's chunk
+  float* scp = STORE_S ? scores + (static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) * sc_pitch(d.Sk) +
+                             (q0 / kTile) * sc_pitch(d.Sk) * kTile + 4 * lane
                        : nullptr;
   float qf[32];                                            // Q[query][32 h + s] * scale: the B operand of S^T = K . Q^T
 #pragma unroll
@@ -255,13 +329,15 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
   const int hole_lo = key_hole ? key_hole[2 * b] : 0, hole_hi = key_hole ? key_hole[2 * b + 1] : 0;
   f32x16 bcur = {0};
   if (HAS_BIAS && active) bcur = load_bias_tile(bp, t_lo * kTile);
+  TileCursor ck = tile_cursor(kb, d.k_ss, d.Sk, t_lo), cv = tile_cursor(vb, d.v_ss, d.Sk, t_lo);
   {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, t_lo * kTile, d.Sk),
-                   tv = load_tile_clamped(vb, d.v_ss, t_lo * kTile, d.Sk);
+    const TileRegs tk = load_tile_next(ck, t_lo), tv = load_tile_next(cv, t_lo);
     store_tile<kKs>(Kbuf[t_lo & 1], tk, 1.0f);
     store_tile_interleaved(Vbuf[t_lo & 1], tv, 1.0f);
   }
   __syncthreads();
+  VQA_STAMP_DECL
+  VQA_STAMP_START();
   for (int kt = t_lo; kt < n_tiles; ++kt) {
     const int k0 = kt * kTile;
     const float* Ks = Kbuf[kt & 1] + r * kKs + 32 * h;
@@ -269,13 +345,15 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
     const bool more = kt + 1 < n_tiles;
     TileRegs tk, tv;
     if (more) {                                  // in flight while this tile is computed
-      tk = load_tile_clamped(kb, d.k_ss, k0 + kTile, d.Sk);
-      tv = load_tile_clamped(vb, d.v_ss, k0 + kTile, d.Sk);
+      tk = load_tile_next(ck, kt + 1);
+      tv = load_tile_next(cv, kt + 1);
     }
+    f32x16 sraw;                                 // the tile's raw scores (live waves of a STORE_S kernel only)
     if (active) {
       f32x16 bnext = {0};
       if (HAS_BIAS && more) bnext = load_bias_tile(bp, k0 + kTile);
       __builtin_amdgcn_sched_barrier(0);         // keep every load ahead of the MFMA chain that hides its latency
+      VQA_STAMP(0);                              // segment 0: the prefetches' address work and issue
       f32x16 st = bcur;                          // S^T = bias + K . (scale Q)^T, key on the accumulator row
       if (k0 < hole_hi && k0 + kTile > hole_lo) {   // a tile that overlaps the hole (at most two of ~19): -inf goes into
 #pragma unroll                                      // the initial accumulator, so the saved scores carry it too
@@ -286,11 +364,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
       }
 #pragma unroll
       for (int s = 0; s < 32; ++s) st = mfma(Ks[s], qf[s], st);
-      if (STORE_S) {                             // the backward's dK / dV kernel starts from these instead of Q . K^T
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(scp + k0 + 8 * g) = f32x4{st[4 * g], st[4 * g + 1], st[4 * g + 2], st[4 * g + 3]};
-      }
+      VQA_STAMP(1);                              // segment 1: the S chain's issue (its last MFMA still runs)
+      if (STORE_S) sraw = st;                    // stored at the end of the tile (see there)
       if (k0 + kTile > d.Sk) {                   // last, partial tile: keys beyond Sk never win the softmax
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = k0 + acc_row(i, h) < d.Sk ? st[i] : -INFINITY;
@@ -318,20 +393,37 @@ __global__ __launch_bounds__(kBlock, 2) void attn_fwd_kernel(const float* __rest
         st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -mc));
         l += st[i];
       }
+      VQA_STAMP(2);                              // segment 2: score store, maximum, exponentials (waits for the chain)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {             // O^T += V^T . P^T, k-pair of step i = keys r0(i), r0(i) + 4
         const f32x2 vv = *reinterpret_cast<const f32x2*>(Vs + ((i & 3) + 8 * (i >> 2)) * kVi);
         o0 = mfma(vv[0], st[i], o0);
         o1 = mfma(vv[1], st[i], o1);
       }
+      VQA_STAMP(3);                              // segment 3: the P . V chains' issue
       bcur = bnext;
     }
     if (more) {                                  // the other buffer was last read one tile ago (barrier in between)
       store_tile<kKs>(Kbuf[(kt + 1) & 1], tk, 1.0f);
       store_tile_interleaved(Vbuf[(kt + 1) & 1], tv, 1.0f);
     }
+    VQA_STAMP(4);                                // segment 4: wait for the prefetched tile, publish it in LDS
+    // The scores the backward's dK / dV kernel starts from (instead of Q . K^T) leave HERE, after the prefetched tile
+    // has been taken out of its registers: the compiler counts loads and stores in one counter and, with stores
+    // pending, waits for ALL of it before the first use of a load -- stored right after the chain, every tile ended
+    // waiting for its own score stores to be acknowledged (12 % of the kernel, tools/attn_ab.py ABLATE=1).  Now the
+    // next wait that covers them is a whole tile away.
+    if (STORE_S && active && !VQA_ABLATE(1)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(scp + static_cast<long>(kt) * kBlockFloats + 256 * g) =
+            f32x4{sraw[4 * g], sraw[4 * g + 1], sraw[4 * g + 2], sraw[4 * g + 3]};
+    }
+    VQA_STAMP(5);                                // segment 5: the score stores' issue
     __syncthreads();
+    VQA_STAMP(6);                                // segment 6: the barrier
   }
+  if (active) VQA_STAMP_FLUSH(0, n_tiles - t_lo);
   if (SPLIT) {                                   // partial: unnormalised accumulators + (max * log2 e, row sum)
     if (qi < d.Sq) {
       l = halves_sum(l);
@@ -447,8 +539,9 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
   const float nlc = -lse[row] * kLog2e;                    // P = exp2(S log2 e - LSE log2 e)
   f32x16 dq0 = {0}, dq1 = {0};
   const int n_tiles = (d.Sk + kTile - 1) / kTile;
+  TileCursor ck = tile_cursor(kb, d.k_ss, d.Sk, 0), cv = tile_cursor(vb, d.v_ss, d.Sk, 0);
   {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk), tv = load_tile_clamped(vb, d.v_ss, 0, d.Sk);
+    const TileRegs tk = load_tile_next(ck, 0), tv = load_tile_next(cv, 0);
     store_tile_interleaved(Kbuf[0], tk, 1.0f);
     store_tile_interleaved(Vbuf[0], tv, 1.0f);
   }
@@ -461,8 +554,8 @@ __global__ __launch_bounds__(kBlock, 3) void attn_bwd_dq_kernel(const float* __r
     const bool more = kt + 1 < n_tiles;
     TileRegs tk, tv;
     if (more) {
-      tk = load_tile_clamped(kb, d.k_ss, k0 + kTile, d.Sk);
-      tv = load_tile_clamped(vb, d.v_ss, k0 + kTile, d.Sk);
+      tk = load_tile_next(ck, kt + 1);
+      tv = load_tile_next(cv, kt + 1);
     }
     if (active) {
       f32x16 st = {0}, dp = {0};
@@ -560,30 +653,32 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
   const int qi = q0 + r;
   const bool active = q0 < d.Sq;
   const float* kb = k + b * d.k_sb + head * d.k_sh;
-  const long pitch = ds_pitch(d.Sq);
-  const float* slab = ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * pitch;     // uniform
-  // staging role of this thread: key row (t / 32) + 8 j of the tile, queries Q0 + 4 (t % 32) .. + 3
-  const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
-  const bool col_ok = Q0 + scol < pitch;                     // the last query block may reach beyond the row pitch
-  const float* dsrc = slab + static_cast<long>(srow) * pitch + (col_ok ? Q0 + scol : 0);
-  auto load_ds = [&](int k0) {
+  // staging role of this thread: 16-byte chunk t of each of the four 32 x 32 tiles (queries Q0 + 32 j ..) of a key tile,
+  // consecutive in the blocked dS^T slab; chunk t = 64 g + 32 hh + rr holds dS^T[key rr][queries 8 g + 4 hh .. + 3]
+  const long tile_row = ds_pitch(d.Sq) * kTile;              // floats per key tile of the slab
+  const float* dsrc = ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * ds_pitch(d.Sq) +
+                      static_cast<long>(Q0 / kTile) * kBlockFloats + 4 * threadIdx.x;
+  const int st_g = threadIdx.x >> 6, st_hh = (threadIdx.x >> 5) & 1, st_rr = threadIdx.x & 31;
+  const int st_off = st_rr * kDsStride + 8 * st_g + 4 * st_hh;
+  auto load_ds = [&](int kt) {
     DsRegs t;
 #pragma unroll
     for (int j = 0; j < 4; ++j)                  // read exactly once
-      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dsrc + static_cast<long>(k0 + 8 * j) * pitch));
+      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dsrc + kt * tile_row + j * kBlockFloats));
     return t;
   };
   auto store_ds = [&](float* buf, const DsRegs& t) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + st_off + kTile * j) = t.v[j];
   };
   f32x16 dq0 = {0}, dq1 = {0};
   const int all_tiles = (d.Sk + kTile - 1) / kTile;
   const int t_lo = SPLIT ? part * all_tiles / nsp : 0;
   const int n_tiles = SPLIT ? (part + 1) * all_tiles / nsp : all_tiles;
+  TileCursor ck = tile_cursor(kb, d.k_ss, d.Sk, t_lo);
   {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, t_lo * kTile, d.Sk);
-    const DsRegs td = load_ds(t_lo * kTile);
+    const TileRegs tk = load_tile_next(ck, t_lo);
+    const DsRegs td = load_ds(t_lo);
     store_tile_interleaved(Kbuf[t_lo & 1], tk, 1.0f);
     store_ds(Dbuf[t_lo & 1], td);
   }
@@ -595,8 +690,8 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
     TileRegs tk;
     DsRegs td;
     if (more) {                                  // in flight while this tile's 32 MFMAs run
-      tk = load_tile_clamped(kb, d.k_ss, (kt + 1) * kTile, d.Sk);
-      td = load_ds((kt + 1) * kTile);
+      tk = load_tile_next(ck, kt + 1);
+      td = load_ds(kt + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
@@ -630,90 +725,15 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_staged_kernel(const flo
   }
 }
 
-#ifdef VQA_TUNING   // round 3's direct form, kept for the A/B of tools/attn_bench.py (option 9); not in the shipped library
-// dQ^T += K^T . dS^T over the key tiles; one workgroup = 4 waves = 128 queries of one (batch, head).  No scores, no
-// exponentials: per tile 16 coalesced dword loads of dS^T (prefetched a tile ahead), 16 LDS reads, 32 MFMAs.
-__global__ __launch_bounds__(kBlock, 2) void attn_bwd_dq_from_ds_kernel(const float* __restrict__ k,
-                                                                        const float* __restrict__ ds,
-                                                                        float* __restrict__ dq, AttnDims d, long dq_sb,
-                                                                        long dq_ss, long dq_sh) {
-  __shared__ __attribute__((aligned(16))) float Kbuf[2][kTile * kVi];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int r = lane & 31, h = lane >> 5;
-  const BlockCoord bc = block_coord((d.Sq + 127) / 128, d.B, d.H);
-  const int b = bc.b, head = bc.head;
-  const int q0 = bc.blk * 128 + wave * kTile;
-  const int qi = q0 + r;
-  const bool active = q0 < d.Sq;
-  const float* kb = k + b * d.k_sb + head * d.k_sh;
-  const long pitch = ds_pitch(d.Sq);
-  const float* slab = ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * pitch;     // uniform
-  // an active wave's queries are < ceil32(Sq) = the pitch; a wave past the last query reads column 0 and discards it
-  const unsigned voff = static_cast<unsigned>(4 * h * pitch + (active ? qi : 0));
-  auto load_ds = [&](int k0) {
-    f32x16 t;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)                  // read exactly once
-      t[i] = __builtin_nontemporal_load(slab + static_cast<long>(k0 + (i & 3) + 8 * (i >> 2)) * pitch + voff);
-    return t;
-  };
-  f32x16 dq0 = {0}, dq1 = {0};
-  const int n_tiles = (d.Sk + kTile - 1) / kTile;
-  // One tile: prefetch the next tile's K rows and dS^T values, run this tile's 32 MFMAs, publish the K tile.  Two
-  // register sets for dS^T alternate (the loop is unrolled by two) instead of "cur = next" copies: a copy would make the
-  // wave wait for the prefetch at the end of the tile it was issued in, and these loads come from HBM.  The prefetch
-  // is unconditional (the last tile prefetches itself again): straight-line code lets the compiler count exactly how
-  // many younger loads may stay in flight at each wait.
-  auto tile = [&](int kt, const f32x16& cur, f32x16& nxt) {
-    const int kn = kt + 1 < n_tiles ? kt + 1 : kt;
-    const float* Kc = Kbuf[kt & 1] + 4 * h * kVi + 2 * r;
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, kn * kTile, d.Sk);
-    nxt = load_ds(kn * kTile);                  // also in a wave without queries (clamped column): no branch around loads
-    __builtin_amdgcn_sched_barrier(0);
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const f32x2 kk = *reinterpret_cast<const f32x2*>(Kc + ((i & 3) + 8 * (i >> 2)) * kVi);
-        dq0 = mfma(kk[0], cur[i], dq0);
-        dq1 = mfma(kk[1], cur[i], dq1);
-      }
-    }
-    store_tile_interleaved(Kbuf[(kt + 1) & 1], tk, 1.0f);      // last read one tile ago, a barrier in between
-    __syncthreads();
-  };
-  f32x16 ds_a = load_ds(0), ds_b = {0};
-  {
-    const TileRegs tk = load_tile_clamped(kb, d.k_ss, 0, d.Sk);
-    store_tile_interleaved(Kbuf[0], tk, 1.0f);
-  }
-  __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < n_tiles; kt += 2) {
-    tile(kt, ds_a, ds_b);
-    tile(kt + 1, ds_b, ds_a);
-  }
-  if (kt < n_tiles) tile(kt, ds_a, ds_b);
-  if (qi < d.Sq) {
-    float* dp_ = dq + b * dq_sb + head * dq_sh + static_cast<long>(qi) * dq_ss;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int dim = 8 * g + 4 * h;
-      f32x4 a = {dq0[4 * g] * d.scale, dq0[4 * g + 1] * d.scale, dq0[4 * g + 2] * d.scale, dq0[4 * g + 3] * d.scale};
-      f32x4 c = {dq1[4 * g] * d.scale, dq1[4 * g + 1] * d.scale, dq1[4 * g + 2] * d.scale, dq1[4 * g + 3] * d.scale};
-      *reinterpret_cast<f32x4*>(dp_ + dim) = a;
-      *reinterpret_cast<f32x4*>(dp_ + 32 + dim) = c;
-    }
-  }
-}
-#endif  // VQA_TUNING
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // One workgroup = 4 waves = 128 keys of one (batch, head); loop over query tiles of 32.  Key on the lane:
 //   S = bias + (scale Q) . K^T (query rows in the accumulator),  P = exp(S - LSE),  dP = dO . V^T,
 //   dS = P o (dP - delta),  dV^T += dO^T . P,  dK^T += (scale Q)^T . dS  (both sum over the query = the accumulators'
-//   row index).  The per-query constants -LSE log2 e and delta ride in LDS next to the tiles, four consecutive
-//   accumulator rows per 16-byte read; the bias of this lane's key for the tile's query rows is 16 dword loads from a
-//   uniform row base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator.
+//   row index).  The per-query constants -LSE log2 e and -delta ride in LDS next to the tiles, four consecutive
+//   accumulator rows per 16-byte read; -delta is the INITIAL accumulator of the dP chain (dS = P o dP is then one
+//   multiply per element); the bias of this lane's key for the tile's query rows is 16 dword loads from a uniform row
+//   base + a per-lane 32-bit offset, prefetched one tile ahead into the initial accumulator of the S chain.
 template <bool HAS_BIAS, bool STORE_DS, bool FROM_SCORES, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
@@ -749,17 +769,16 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const float* vp = v + b * d.v_sb + head * d.v_sh + static_cast<long>(kl) * d.v_ss + 32 * h;
   const float* qb = q + b * d.q_sb + head * d.q_sh;
   const float* gb = go + b * go_sb + head * go_sh;
-  // The S chain's initial accumulator: the bias tile -- or, when the forward saved its scores (bias included), the
-  // scores themselves, and the chain is not run at all.  Either way a (query row, key) matrix of one (batch, head).
-  constexpr bool kInit = HAS_BIAS || FROM_SCORES;
-  const long init_sr = FROM_SCORES ? sc_pitch(d.Sk) : d.bias_sr;
-  const float* bslab = FROM_SCORES ? scores + (static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) * sc_pitch(d.Sk)
-                       : HAS_BIAS  ? bias + b * d.bias_sb + head * d.bias_sh
-                                   : nullptr;                                          // uniform
+  // The S chain's initial accumulator is the bias tile, a (query row, key) matrix of one (batch, head) -- unless the
+  // forward saved its scores (bias included): then the scores replace the chain (they come through LDS, see below).
+  constexpr bool kInit = HAS_BIAS && !FROM_SCORES;
+  const long init_sr = d.bias_sr;
+  const float* bslab = kInit ? bias + b * d.bias_sb + head * d.bias_sh : nullptr;      // uniform
   const unsigned bvoff = kInit ? static_cast<unsigned>(kl + 4 * h * static_cast<int>(init_sr)) : 0u;
   const long rows = (static_cast<long>(b) * d.H + head) * d.Sq;
-  // dS^T[(batch, head)][key][query], pitches ceil128(Sk) x ceil32(Sq): this lane's row, at its half's query offset
-  float* dsp = STORE_DS ? ds + ((static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) + ki) * ds_pitch(d.Sq) + 4 * h
+  // dS^T: this wave's row of tiles (key tile 4 blk + wave) in the blocked slab, at this lane's chunk
+  float* dsp = STORE_DS ? ds + (static_cast<long>(b) * d.H + head) * ds_rows(d.Sk) * ds_pitch(d.Sq) +
+                              (4 * bc.blk + wave) * ds_pitch(d.Sq) * kTile + 4 * lane
                         : nullptr;
   float kf[32], vf[32];
 #pragma unroll
@@ -776,12 +795,24 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
   const int all_tiles = (d.Sq + kTile - 1) / kTile;
   const int t_lo = SPLIT ? part * all_tiles / nsp : 0;       // this workgroup's query tiles [t_lo, n_tiles)
   const int n_tiles = SPLIT ? (part + 1) * all_tiles / nsp : all_tiles;
-  // per-query row constants of a tile: thread t < 32 carries (-lse log2 e, delta) of query q0 + t
+  // per-query row constants of a tile: wave 0 fetches (lse, delta) of query q0 + lane % 32 a tile ahead, RAW and from a
+  // clamped row -- the values are first touched when they are published in LDS as (-lse log2 e, -delta), a tile later,
+  // where queries beyond Sq get (-inf, 0): P = exp2(-inf) = 0.  No branch on the lane and no default value around the
+  // loads: scaling at the load made wave 0 wait for them -- and, vmcnt being in order, for the Q / dO / score tiles issued
+  // before them -- at the top of every tile, and the other three waves for wave 0 at the barrier (tools/attn_stamps.py).
+  const bool rc_wave = __builtin_amdgcn_readfirstlane(wave) == 0;
   auto row_consts = [&](int q0, float& rl, float& rd) {
-    const int qq = q0 + static_cast<int>(threadIdx.x);
-    const bool ok = threadIdx.x < kTile && qq < d.Sq;
-    rl = ok ? -lse[rows + qq] * kLog2e : -INFINITY;                  // a query beyond Sq: P = exp2(-inf) = 0
-    rd = ok ? delta[rows + qq] : 0.0f;
+    int qq = q0 + r;
+    qq = qq < d.Sq ? qq : d.Sq - 1;
+    rl = lse[rows + qq];
+    rd = delta[rows + qq];
+  };
+  auto publish_consts = [&](int bi, int q0, float rl, float rd) {
+    if (threadIdx.x < kTile) {
+      const bool ok = q0 + static_cast<int>(threadIdx.x) < d.Sq;
+      Lbuf[bi][threadIdx.x] = ok ? -rl * kLog2e : -INFINITY;
+      Dbuf[bi][threadIdx.x] = ok ? -rd : 0.0f;
+    }
   };
   // bias[query q0 + acc_row(i, h)][this key]: a full tile reads from uniform row bases; the last, partial query tile
   // clamps the row per lane (its P is 0 whatever is read)
@@ -800,40 +831,46 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     }
     return t;
   };
-  // staging role of this thread for the score tile: query row (t / 32) + 8 j, keys K0 + 4 (t % 32) .. + 3
-  const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
-  const bool scol_ok = FROM_SCORES && bc.blk * 128 + scol < sc_pitch(d.Sk);     // the last key block may pass the pitch
-  const float* ssp = FROM_SCORES ? bslab + (scol_ok ? bc.blk * 128 + scol : 0) : nullptr;
-  auto load_scores = [&](int q0) {
+  // staging role of this thread for the score tile: 16-byte chunk t of each of the four 32 x 32 tiles (keys K0 + 32 j ..)
+  // of a query tile, consecutive in the blocked slab; chunk t = 64 g + 32 hh + rr holds S[query rr][keys 8 g + 4 hh .. + 3].
+  // Rows beyond Sq: the forward that saved the scores wrote the whole tile of every live wave -- finite scores of the
+  // clamped last query (or -inf) -- and their P is exp2(s log2 e - inf) = 0.
+  const long sc_tile_row = sc_pitch(d.Sk) * kTile;           // floats per query tile of the slab
+  const float* sptr = FROM_SCORES ? scores + (static_cast<long>(b) * d.H + head) * sc_rows(d.Sq) * sc_pitch(d.Sk) +
+                                        t_lo * sc_tile_row + static_cast<long>(4 * bc.blk) * kBlockFloats + 4 * threadIdx.x
+                                  : nullptr;
+  const int st_off = (threadIdx.x & 31) * kDsStride + 8 * (threadIdx.x >> 6) + 4 * ((threadIdx.x >> 5) & 1);
+  auto load_scores_next = [&]() {
     DsRegs t;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                // rows beyond Sq are clamped (their P is 0 whatever is read)
-      const int qq = q0 + srow + 8 * j;
-      t.v[j] = __builtin_nontemporal_load(
-          reinterpret_cast<const f32x4*>(ssp + static_cast<long>(qq < d.Sq ? qq : d.Sq - 1) * init_sr));
-    }
+    for (int j = 0; j < 4; ++j)
+      t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sptr + j * kBlockFloats));
+    sptr += sc_tile_row;
     return t;
   };
   auto store_scores = [&](float* buf, const DsRegs& t) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * kDsStride + scol) = t.v[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + st_off + kTile * j) = t.v[j];
   };
   f32x16 bcur = {0};
-  if (kInit && !FROM_SCORES && active) bcur = load_bias(t_lo * kTile);
+  if (kInit && active) bcur = load_bias(t_lo * kTile);
+  // Q in LDS: scaled where the S chain reads it; with saved scores it only feeds dK^T += Q^T . dS, and the scale is
+  // applied to the 32 dK accumulators once, after the loop, instead of to 8 tile values per thread and tile
+  const float q_mul = FROM_SCORES ? 1.0f : d.scale, dk_mul = FROM_SCORES ? d.scale : 1.0f;
+  TileCursor cq = tile_cursor(qb, d.q_ss, d.Sq, t_lo), cg = tile_cursor(gb, go_ss, d.Sq, t_lo);
+  float rl = 0.0f, rd = 0.0f;                      // wave 0's prefetched row constants
   {
     const int qs = t_lo * kTile, bi = t_lo & 1;
-    const TileRegs tq = load_tile_clamped(qb, d.q_ss, qs, d.Sq), tg = load_tile_clamped(gb, go_ss, qs, d.Sq);
-    float rl, rd;
-    row_consts(qs, rl, rd);
-    if (FROM_SCORES) store_scores(Sbuf[FROM_SCORES ? bi : 0], load_scores(qs));
-    store_tile_interleaved(Qbuf[bi], tq, d.scale);
+    const TileRegs tq = load_tile_next(cq, t_lo), tg = load_tile_next(cg, t_lo);
+    if (rc_wave) row_consts(qs, rl, rd);
+    if (FROM_SCORES) store_scores(Sbuf[FROM_SCORES ? bi : 0], load_scores_next());
+    store_tile_interleaved(Qbuf[bi], tq, q_mul);
     store_tile_interleaved(Gbuf[bi], tg, 1.0f);
-    if (threadIdx.x < kTile) {
-      Lbuf[bi][threadIdx.x] = rl;
-      Dbuf[bi][threadIdx.x] = rd;
-    }
+    publish_consts(bi, qs, rl, rd);
   }
   __syncthreads();
+  VQA_STAMP_DECL
+  VQA_STAMP_START();
   for (int qt = t_lo; qt < n_tiles; ++qt) {
     const int q0 = qt * kTile;
     const float* Qr = Qbuf[qt & 1] + r * kVi + h;          // row read: Q[query r][32 h + s] at Qr[2 s]
@@ -845,55 +882,57 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
     const bool more = qt + 1 < n_tiles;
     TileRegs tq, tg;
     DsRegs ts;
-    float rl = 0.0f, rd = 0.0f;
     if (more) {
-      tq = load_tile_clamped(qb, d.q_ss, q0 + kTile, d.Sq);
-      tg = load_tile_clamped(gb, go_ss, q0 + kTile, d.Sq);
-      if (FROM_SCORES) ts = load_scores(q0 + kTile);
-      row_consts(q0 + kTile, rl, rd);
+      tq = load_tile_next(cq, qt + 1);
+      tg = load_tile_next(cg, qt + 1);
+      if (FROM_SCORES) ts = load_scores_next();
+      if (rc_wave) row_consts(q0 + kTile, rl, rd);
     }
+    f32x16 dp;                                     // dP, then dS (live waves only)
     if (active) {
       f32x16 bnext = {0};
-      if (!FROM_SCORES && kInit && more) bnext = load_bias(q0 + kTile);
+      if (kInit && more) bnext = load_bias(q0 + kTile);
       __builtin_amdgcn_sched_barrier(0);
-      f32x16 st = bcur, dp = {0};
-      if (FROM_SCORES) {
+      VQA_STAMP(0);                                // segment 0: the prefetches' address work and issue
+      // dP's chain starts from -delta of its query rows (the accumulator's rows), so dS = P o dP needs no subtraction
+      f32x16 st = bcur;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) dp = mfma(Gr[2 * s], vf[s], dp);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(Ds + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
+      }
+      if (FROM_SCORES) {                           // P first: its LDS reads and exponentials need no matrix result
         const float* Sc = Sbuf[qt & 1] + 4 * h * kDsStride + wave * kTile + r;   // S[query rowi][this lane's key]
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = Sc[((i & 3) + 8 * (i >> 2)) * kDsStride];
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 nl = *reinterpret_cast<const f32x4*>(Ls + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[((i & 3) + 8 * (i >> 2)) * kDsStride], kLog2e, nl[e]));
+          }
+        }
+        VQA_STAMP(1);                              // segment 1: LDS reads of -delta, S, -LSE; 16 exponentials
+#pragma unroll
+        for (int s = 0; s < 32; ++s) dp = mfma(Gr[2 * s], vf[s], dp);
+        VQA_STAMP(2);                              // segment 2: the dP chain's issue
       } else {
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
           st = mfma(Qr[2 * s], kf[s], st);
           dp = mfma(Gr[2 * s], vf[s], dp);
         }
-      }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 nl = *reinterpret_cast<const f32x4*>(Ls + 8 * g);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(Ds + 8 * g);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 nl = *reinterpret_cast<const f32x4*>(Ls + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, nl[e]));   // P
-          dp[i] = st[i] * (dp[i] - dl[e]);                                         // dS
+          for (int e = 0; e < 4; ++e) st[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[4 * g + e], kLog2e, nl[e]));   // P
         }
       }
-      if (STORE_DS) {                              // four consecutive queries per 16-byte store
-        if (all_live) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(dsp + q0 + 8 * g) = f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]};
-        } else {                                   // the wave that straddles Sk: zeros in the rows of keys beyond it
-          const bool live = ki < d.Sk;
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(dsp + q0 + 8 * g) =
-                live ? f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-      }
+      for (int i = 0; i < 16; ++i) dp[i] *= st[i];                                     // dS
+      VQA_STAMP(3);                                // segment 3: dS (waits for the chain's last MFMA)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int off = ((i & 3) + 8 * (i >> 2)) * kVi;
@@ -904,19 +943,38 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
         dk0 = mfma(qq[0], dp[i], dk0);
         dk1 = mfma(qq[1], dp[i], dk1);
       }
+      VQA_STAMP(4);                                // segment 4: the dV / dK chains' issue
       if (!FROM_SCORES) bcur = bnext;
     }
     if (more) {
-      store_tile_interleaved(Qbuf[(qt + 1) & 1], tq, d.scale);
+      store_tile_interleaved(Qbuf[(qt + 1) & 1], tq, q_mul);
       store_tile_interleaved(Gbuf[(qt + 1) & 1], tg, 1.0f);
       if (FROM_SCORES) store_scores(Sbuf[(qt + 1) & 1], ts);
-      if (threadIdx.x < kTile) {
-        Lbuf[(qt + 1) & 1][threadIdx.x] = rl;
-        Dbuf[(qt + 1) & 1][threadIdx.x] = rd;
+      asm volatile("" : "+v"(rl), "+v"(rd));      // the raw values are first needed HERE (the compiler would scale at the load)
+      publish_consts((qt + 1) & 1, q0 + kTile, rl, rd);
+    }
+    VQA_STAMP(5);                                  // segment 5: wait for the prefetched tiles, publish them in LDS
+    // dS^T leaves here, after the prefetched tiles have been taken out of their registers -- see the forward's score
+    // stores: with stores pending the compiler's wait for a load is a wait for everything
+    if (STORE_DS && active && !VQA_ABLATE(1)) {    // four consecutive queries per 16-byte store
+      if (all_live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(dsp + static_cast<long>(qt) * kBlockFloats + 256 * g) =
+              f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]};
+      } else {                                     // the wave that straddles Sk: zeros in the rows of keys beyond it
+        const bool live = ki < d.Sk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(dsp + static_cast<long>(qt) * kBlockFloats + 256 * g) =
+              live ? f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
+    VQA_STAMP(6);                                  // segment 6: the dS^T stores' issue
     __syncthreads();
+    VQA_STAMP(7);                                  // segment 7: the barrier
   }
+  if (active) VQA_STAMP_FLUSH(1, n_tiles - t_lo);
   if (ki < d.Sk) {
     const long rows = static_cast<long>(d.B) * d.H * d.Sk;
     const long row = (static_cast<long>(b) * d.H + head) * d.Sk + ki;
@@ -926,8 +984,10 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dim = 8 * g + 4 * h;
-      *reinterpret_cast<f32x4*>(pk + dim) = f32x4{dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]};
-      *reinterpret_cast<f32x4*>(pk + 32 + dim) = f32x4{dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(pk + dim) =
+          f32x4{dk0[4 * g] * dk_mul, dk0[4 * g + 1] * dk_mul, dk0[4 * g + 2] * dk_mul, dk0[4 * g + 3] * dk_mul};
+      *reinterpret_cast<f32x4*>(pk + 32 + dim) =
+          f32x4{dk1[4 * g] * dk_mul, dk1[4 * g + 1] * dk_mul, dk1[4 * g + 2] * dk_mul, dk1[4 * g + 3] * dk_mul};
       *reinterpret_cast<f32x4*>(pv + dim) = f32x4{dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]};
       *reinterpret_cast<f32x4*>(pv + 32 + dim) = f32x4{dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]};
     }
@@ -938,14 +998,18 @@ __global__ __launch_bounds__(kBlock, 2) void attn_bwd_dkv_kernel(const float* __
 
 using namespace vqa;
 
-VQA_KNOB g_attn_dq_staged = 1;      // option 9 (tuning build): 1 = dS^T tile staged through LDS, 0 = direct dword loads
-
 extern "C" {
 
 #ifdef VQA_TUNING
-int vqa_attn_set_option(int value) {     // reached through vqa_set_option(9, value)
-  g_attn_dq_staged = value ? 1 : 0;
-  return VQA_OK;
+int vqa_attn_set_option(int value) {     // vqa_set_option(9, value): round 3's A/B of the dQ kernel, gone with the blocked dS^T
+  return VQA_ERR_SHAPE;
+}
+int vqa_attn_set_ablation(int bits) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(vqa::d_attn_ablate), &bits, sizeof(bits)) == hipSuccess ? VQA_OK : VQA_ERR_NULL;
+}
+// 20 zeroed 64-bit words on the device (forward: 0..9, dK / dV kernel: 10..19), or NULL to switch the stamps off
+int vqa_attn_set_stamps(unsigned long long* buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(vqa::d_attn_stamps), &buffer, sizeof(buffer)) == hipSuccess ? VQA_OK : VQA_ERR_NULL;
 }
 #endif
 
@@ -1111,10 +1175,6 @@ int vqa_attn_bwd(const float* q, const float* k, const float* v, const float* bi
       attn_bwd_dkv_kernel<false, true, false><<<gk, kBlock, 0, st>>>(q, k, v, bias, go, lse, delta, dk, dv, d, g[6],
                                                                      g[7], g[8], g[9], g[10], g[11], g[0], g[1], g[2],
                                                                      ds_ws, nullptr, sp);
-#ifdef VQA_TUNING
-    if (!g_attn_dq_staged) attn_bwd_dq_from_ds_kernel<<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5]);
-    else
-#endif
     attn_bwd_dq_staged_kernel<false><<<gq, kBlock, 0, st>>>(k, ds_ws, dq, d, g[3], g[4], g[5], sp);
   } else if (bias) {                             // no workspace: 7 products, both kernels recompute the scores
     attn_bwd_dq_kernel<true><<<gq, kBlock, 0, st>>>(q, k, v, bias, o, go, lse, delta, dq, d, g[3], g[4], g[5], g[0], g[1],
