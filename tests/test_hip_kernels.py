@@ -233,6 +233,38 @@ def test_neg_cos_rows(rows0, rows1, d):
     assert abs(float(slot.item())) <= 1e-4 * max(1.0, abs(float(want_loss)))
 
 
+@pytest.mark.parametrize("d", [768, 1024])
+def test_whole_chunk_rows_kernel_equals_the_general_one(d):
+    """Rows of NCH * 256 floats of a token map (rows1 > 128) run on the branch-free kernel (csrc/loss.hip,
+    neg_cos_rows_full_kernel); the same rows viewed as a map of <= 128 rows per sample -- with the same weights -- run on
+    the general one.  Gradients must agree bit for bit (weight-0 rows exactly zero), the loss to fp32 summation order.
+    A NaN in a weight-0 row (which only the new kernel reads) must not reach the loss or the gradient."""
+    ops = _ops()
+    r = np.random.RandomState(31)
+    a = torch.from_numpy(r.standard_normal((6, 256, d)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(r.standard_normal((6, 256, d)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((r.uniform(size=(6, 256)) > 0.2).astype(np.uint8))
+    w[:, 0] = 2
+    w[:, 255] = 0                                           # the last row of every sample is padding
+    a[1, 255] = float("nan")
+    a[0, 0] = 0.0
+    w = w.to(DEV)
+    s_full, s_gen = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    g_full = ops.neg_cos_rows(a, b, s_full, accumulate=False, row_weight=w, weight_period=6).clone()
+    g_gen = ops.neg_cos_rows(a.view(12, 128, d), b.view(12, 128, d), s_gen, accumulate=False,
+                             row_weight=w.view(12, 128), weight_period=12).clone()
+    assert torch.equal(g_full.view(-1, d), g_gen.view(-1, d))
+    assert not torch.isnan(g_full).any() and float(g_full[1, 255].abs().max()) == 0.0
+    assert torch.allclose(s_full, s_gen, rtol=1e-6, atol=0.0)
+    # no weights: the whole-chunk kernel for any rows1
+    s2 = torch.zeros(1, device=DEV)
+    a[1, 255] = 1.0
+    g2 = ops.neg_cos_rows(a, b, s2, accumulate=False)
+    want_loss, want_grad = _cos_ref(a.cpu(), b.cpu())
+    assert torch.allclose(s2.cpu()[0], want_loss, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(g2.cpu(), want_grad, rtol=1e-4, atol=1e-6)
+
+
 def test_neg_cos_rows_strided_views_2d_and_mask():
     ops = _ops()
     r = np.random.RandomState(24)

@@ -154,6 +154,16 @@ def cos_section(b):
     report("vqa_neg_cos_rows_multi ({} layers, row weights)".format(n_layers), 12 * live * 768 * n_layers,
            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
                   reps=10))
+    for full in (0, 1, 0, 1):                 # option 12: the general row kernel vs the branch-free whole-chunk one
+        if not _hip.set_option(12, full):
+            break
+        report("vqa_neg_cos_rows_multi ({} layers, row weights) [{}]".format(
+            n_layers, "neg_cos_rows_full_kernel" if full else "neg_cos_rows_kernel (general)"), 12 * live * 768 * n_layers,
+            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, row_weight=w, weight_period=b, ws=ws),
+                   reps=10), "A/B, alternating")
+        report("vqa_neg_cos_rows_multi ({} layers, no weights) [{}]".format(
+            n_layers, "neg_cos_rows_full_kernel" if full else "neg_cos_rows_kernel (general)"), 12 * rows * 768 * n_layers,
+            timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B, alternating")
     for nt in (0, 5, 6, 7, 4):
         if not _hip.set_option(8, nt):
             break

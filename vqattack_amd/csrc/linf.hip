@@ -257,6 +257,8 @@ int vqa_set_option(int option, int value) {
       return vqa_attn_set_option(value);
     case 10:
       return vqa_block_set_option(value);
+    case 12:
+      return vqa_loss_set_option(option, value);
     default:
       return VQA_ERR_SHAPE;
   }

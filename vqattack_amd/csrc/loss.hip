@@ -160,12 +160,41 @@ __device__ __forceinline__ float block_sum_ordered(const float* p, int count, fl
   return s;
 }
 
+// Workgroup epilogue of both row kernels: 4-wave combine of the per-wave sums, publish the partial, and -- in the fold
+// mode -- the workgroup that arrives last folds all partials in index order into the scalar loss.
+__device__ __forceinline__ void finish_block(float acc, int lane, int wave, float* __restrict__ partial, const Fold& fold) {
+  __shared__ float lds[kWavesPerBlock];
+  __shared__ int lds_last;
+  if (lane == 0) lds[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = lds[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) s += lds[w];
+    if (fold.counter) {
+      // publish write-through (agent scope), drain, then count this workgroup in: the last one to arrive folds
+      __hip_atomic_store(partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lds_last = arrive_is_last(fold.counter) ? 1 : 0;
+    } else {
+      partial[blockIdx.x] = s;
+      lds_last = 0;
+    }
+  }
+  if (!fold.counter && blockIdx.x == 0)     // partials-only mode: unused slots read as zero by vqa_sum_partials
+    for (int i = gridDim.x + threadIdx.x; i < kLossMaxBlocks; i += kBlock) partial[i] = 0.0f;
+  __syncthreads();
+  if (lds_last) {     // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const float s = block_sum_ordered(partial, static_cast<int>(gridDim.x), lds, true) * fold.scale;
+    if (threadIdx.x == 0) fold.loss_out[0] = fold.accumulate ? fold.loss_out[0] + s : s;
+    arrive_reset(fold.counter);                                      // ready for the next launch
+  }
+}
+
 template <int NCH, bool GRAD, bool PIPE2, int NT>
 __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(LayerTable tab, float* __restrict__ partial, Fold fold,
                                                               const uint8_t* __restrict__ row_mask, RowAddr ra,
                                                               int D, float gscale, float cos_eps) {
-  __shared__ float lds[kWavesPerBlock];
-  __shared__ int lds_last;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
   const long per_layer = static_cast<long>(ra.rows0) * ra.rows1;
@@ -200,30 +229,125 @@ __global__ __launch_bounds__(kBlock) void neg_cos_rows_kernel(LayerTable tab, fl
       }
     }
   }
-  if (lane == 0) lds[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = lds[0];
+  finish_block(acc, lane, wave, partial, fold);
+}
+
+// ---------------------------------------------------------------------------------------------- whole-chunk rows
+// The same arithmetic for rows of exactly NCH * 256 floats (768, 1024: every feature map of the bundled encoders), written
+// WITHOUT a branch around any memory instruction.  The compiler counts a wave's outstanding loads and stores in one
+// counter (vmcnt) and lets a wait name "all but the N youngest"; a load or store that only SOME path issues makes N
+// unknown behind the join, and the wait it then writes is for everything.  In the general kernel above (per-lane `d < D`
+// guards, weight-0 rows skipped, the next row loaded only if there is one) that turned "two rows in flight" into: the
+// reduction of a row waits for the NEXT row's loads as well, and each 16-byte piece of the gradient waits for the
+// previous piece's store to be acknowledged (tools/isa_loop_mix.py --waits).  Here every row issues the same
+// instructions: weight-0 rows (padded tokens, < 1 % of the attack's maps) are loaded too and select zeros afterwards,
+// the row after the last one re-reads the last one, and the mask byte is read through a pointer that is always valid.
+// Results are bitwise those of the general kernel.  Measured (13 maps of 64 x 617 x 768, tools/kernel_roofline.py,
+// alternating): 845.7 against 860.0 us without row weights (+1.7 %), 843 against 842 us with 30 of 617 rows padded
+// (it reads the 4.9 % of dead rows the other skips): the launch is bound by the memory system either way, what the
+// exact waits buy is small -- but they are exact.
+template <int NCH, int NT>
+__device__ __forceinline__ void load_row_full(RowRegs<NCH>& r, const Cursor& c, const LayerTable& tab, const RowAddr& ra,
+                                              const uint8_t* __restrict__ row_mask, int lane) {
+  int om = c.o;
+  if (ra.mask_period != ra.rows0) om = (ra.mask_period == 1) ? 0 : c.o % ra.mask_period;
+  const float* __restrict__ pa = tab.a[c.layer] + c.o * ra.a0 + c.i * ra.a1;
+  const float* __restrict__ pb = tab.b[c.layer] + c.o * ra.b0 + c.i * ra.b1;
+  // no mask: the byte comes from the row itself and is not used
+  const uint8_t* mp = row_mask ? row_mask + static_cast<long>(om) * ra.rows1 + c.i : reinterpret_cast<const uint8_t*>(pa);
+  const float wm = static_cast<float>(*mp);
+  r.w = row_mask ? wm : 1.0f;
+  r.g = tab.g[c.layer] ? tab.g[c.layer] + c.o * ra.g0 + c.i * ra.g1 : nullptr;
 #pragma unroll
-    for (int w = 1; w < kWavesPerBlock; ++w) s += lds[w];
-    if (fold.counter) {
-      // publish write-through (agent scope), drain, then count this workgroup in: the last one to arrive folds
-      __hip_atomic_store(partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lds_last = arrive_is_last(fold.counter) ? 1 : 0;
-    } else {
-      partial[blockIdx.x] = s;
-      lds_last = 0;
+  for (int k = 0; k < NCH; ++k) {
+    const int d = (k * kWave + lane) * 4;
+    r.a[k] = (NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + d))
+                      : *reinterpret_cast<const f32x4*>(pa + d);
+    r.b[k] = (NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pb + d))
+                      : *reinterpret_cast<const f32x4*>(pb + d);
+  }
+}
+
+template <int NCH, bool GRAD, int NT>
+__device__ __forceinline__ void reduce_row_full(const RowRegs<NCH>& r, float& acc, int lane, float gscale, float cos_eps) {
+  const bool live = r.w != 0.0f;
+  float dot = 0.0f, na2 = 0.0f, nb2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dot += r.a[k][e] * r.b[k][e];
+      na2 += r.a[k][e] * r.a[k][e];
+      nb2 += r.b[k][e] * r.b[k][e];
     }
   }
-  if (!fold.counter && blockIdx.x == 0)     // partials-only mode: unused slots read as zero by vqa_sum_partials
-    for (int i = gridDim.x + threadIdx.x; i < kLossMaxBlocks; i += kBlock) partial[i] = 0.0f;
-  __syncthreads();
-  if (lds_last) {     // workgroup-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const float s = block_sum_ordered(partial, static_cast<int>(gridDim.x), lds, true) * fold.scale;
-    if (threadIdx.x == 0) fold.loss_out[0] = fold.accumulate ? fold.loss_out[0] + s : s;
-    arrive_reset(fold.counter);                                      // ready for the next launch
+  dot = wave_sum(dot);
+  na2 = wave_sum(na2);
+  nb2 = wave_sum(nb2);
+  if (!live) {                       // what the general kernel computes with for a row it never read
+    dot = 0.0f;
+    na2 = 0.0f;
+    nb2 = 0.0f;
   }
+  const float na = sqrtf(na2), nb = sqrtf(nb2);
+  const float dna = fmaxf(na, cos_eps), dnb = fmaxf(nb, cos_eps);
+  const float inv = 1.0f / (dna * dnb);
+  const float term = -(r.w * (dot * inv));
+  acc += live ? term : 0.0f;
+  if (GRAD) {
+    const float gs = gscale * r.w;
+    const float kb = -gs * inv;
+    const float ka = (na > cos_eps) ? gs * dot * inv / (na * na) : 0.0f;
+    f32x4 o[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = kb * r.b[k][e] + ka * r.a[k][e];
+        o[k][e] = live ? v : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {      // the row's stores back to back, nothing waits between them
+      const int d = (k * kWave + lane) * 4;
+      if (NT & 2) __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(r.g + d));
+      else *reinterpret_cast<f32x4*>(r.g + d) = o[k];
+    }
+  }
+}
+
+template <int NCH, bool GRAD, int NT>
+__global__ __launch_bounds__(kBlock) void neg_cos_rows_full_kernel(LayerTable tab, float* __restrict__ partial, Fold fold,
+                                                                   const uint8_t* __restrict__ row_mask, RowAddr ra,
+                                                                   float gscale, float cos_eps) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
+  const long per_layer = static_cast<long>(ra.rows0) * ra.rows1;
+  const long total = per_layer * ra.n_layers;
+  const long wstride = static_cast<long>(gridDim.x) * kWavesPerBlock;
+  const long first = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave;
+  float acc = 0.0f;
+  if (first < total) {
+    long left = (total - first + wstride - 1) / wstride;      // rows this wave owns
+    Cursor c;
+    c.layer = static_cast<int>(first / per_layer);
+    const long rem = first - c.layer * per_layer;
+    c.o = static_cast<int>(rem / ra.rows1);
+    c.i = static_cast<int>(rem - static_cast<long>(c.o) * ra.rows1);
+    RowRegs<NCH> r0, r1;
+    load_row_full<NCH, NT>(r0, c, tab, ra, row_mask, lane);
+    while (true) {                                            // two rows in flight, registers ping-pong r0 / r1
+      if (left > 1) advance(c, ra);                           // no next row: the cursor stays, the row is read again
+      load_row_full<NCH, NT>(r1, c, tab, ra, row_mask, lane);
+      reduce_row_full<NCH, GRAD, NT>(r0, acc, lane, gscale, cos_eps);
+      if (--left == 0) break;
+      if (left > 1) advance(c, ra);
+      load_row_full<NCH, NT>(r0, c, tab, ra, row_mask, lane);
+      reduce_row_full<NCH, GRAD, NT>(r1, acc, lane, gscale, cos_eps);
+      if (--left == 0) break;
+    }
+  }
+  finish_block(acc, lane, wave, partial, fold);
 }
 
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __restrict__ partial, int count,
@@ -238,13 +362,19 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __res
 VQA_KNOB g_loss_blocks_per_cu = 0;   // option 6: 0 = exactly the resident workgroups, n > 0 = n per CU
 VQA_KNOB g_loss_rows_in_flight = 2;  // option 7: 1 | 2
 VQA_KNOB g_loss_nt = 4;              // option 8: bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b
+VQA_KNOB g_loss_full_rows = 1;       // option 12: rows of NCH * 256 floats take neg_cos_rows_full_kernel (0: the general one)
 
 template <int NCH, bool GRAD, bool PIPE2, int NT>
 static int launch_cos_inst(hipStream_t st, const LayerTable& tab, float* partial, const Fold& fold, const uint8_t* mask,
                            RowAddr ra, int D, float gscale, float eps) {
-  static int occupancy_grid = 0;      // per instantiation: occupancy x CUs
-  if (occupancy_grid == 0) occupancy_grid = resident_blocks(neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT>, kBlock, 6);
-  int resident = g_loss_blocks_per_cu > 0 ? g_loss_blocks_per_cu * cu_count() : occupancy_grid;
+  // whole-chunk rows of token maps take the straight-line kernel; short rows-per-sample maps (text-only: most of a
+  // padded question's rows can be weight 0, and that kernel reads them) keep the one that skips weight-0 rows
+  const bool full = PIPE2 && D == NCH * 256 && g_loss_full_rows && (!mask || ra.rows1 > 128);
+  static int occupancy_grid[2] = {0, 0};      // per instantiation and kernel: occupancy x CUs
+  if (occupancy_grid[full] == 0)
+    occupancy_grid[full] = full ? resident_blocks(neg_cos_rows_full_kernel<NCH, GRAD, NT>, kBlock, 6)
+                                : resident_blocks(neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT>, kBlock, 6);
+  int resident = g_loss_blocks_per_cu > 0 ? g_loss_blocks_per_cu * cu_count() : occupancy_grid[full];
   if (resident > kLossMaxBlocks) resident = kLossMaxBlocks;
   const long total = static_cast<long>(ra.rows0) * ra.rows1 * ra.n_layers;
   long want = (total + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -257,7 +387,10 @@ static int launch_cos_inst(hipStream_t st, const LayerTable& tab, float* partial
     ra.step_o = static_cast<int>(so % ra.rows0);
     ra.step_l = static_cast<int>(so / ra.rows0);
   }
-  neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT><<<grid, kBlock, 0, st>>>(tab, partial, fold, mask, ra, D, gscale, eps);
+  if (full)
+    neg_cos_rows_full_kernel<NCH, GRAD, NT><<<grid, kBlock, 0, st>>>(tab, partial, fold, mask, ra, gscale, eps);
+  else
+    neg_cos_rows_kernel<NCH, GRAD, PIPE2, NT><<<grid, kBlock, 0, st>>>(tab, partial, fold, mask, ra, D, gscale, eps);
   return launch_status();
 }
 
@@ -332,6 +465,10 @@ int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_o
   if (which == 6) {
     if (value < 0 || value > 8) return VQA_ERR_SHAPE;
     g_loss_blocks_per_cu = value;
+    return VQA_OK;
+  }
+  if (which == 12) {
+    g_loss_full_rows = value ? 1 : 0;
     return VQA_OK;
   }
   if (which == 8) {
