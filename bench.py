@@ -509,14 +509,15 @@ class KernelTimer:
             # launches differ in size (text / image rows): total bytes over total time; live-row counts read only now
             total_bytes = sum(int(rows) * per * row_bytes for rows, per, row_bytes in self.loss_rows)
             gbs = total_bytes / (mean_ms * n) / 1e6
-            loss = dict(kernel="vqa_neg_cos_rows_multi (neg_cos_rows_kernel: every per-layer map of a modality in one "
-                               "launch, loss folded in the launch)", bound="hbm", achieved=round(gbs, 1),
+            loss = dict(kernel="vqa_neg_cos_rows_multi (neg_cos_rows_full_kernel: every per-layer map of a modality in "
+                               "one launch, loss folded in the launch)", bound="hbm", achieved=round(gbs, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), launches=n,
                         mean_launch_us=round(mean_ms * 1e3, 2), min_launch_us=round(min_ms * 1e3, 2),
                         algorithmic_bytes_per_launch=round(total_bytes / n),
-                        note="12*D bytes per live row (read a, b; write grad); padded text rows (ragged questions inside "
-                             "the trimmed layout) are not read and cost their zero gradient row (4*D)",
-                        **traffic_fields("neg_cos_rows_kernel", self._loss_shape_record()))
+                        note="12*D bytes per live row (read a, b; write grad) -- the padded text rows (ragged questions "
+                             "inside the trimmed layout, < 1 % of the rows) are not counted: they need only their zero "
+                             "gradient row, although the branch-free kernel reads them as well",
+                        **traffic_fields("neg_cos_rows", self._loss_shape_record()))
         return step, loss
 
 

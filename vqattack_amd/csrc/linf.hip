@@ -12,7 +12,11 @@ namespace vqa {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- launch shape (VQA_KNOB: compile-time constants in the shipped library, see common.hpp)
-VQA_KNOB g_opt_blocks_per_cu = 8;   // option 0
+// option 0: workgroups per CU in the grid.  The step kernel keeps 6 workgroups resident per CU (76 registers: all 12
+// loads of a tile in flight): 12 = two whole rounds.  profiles/r06/step/step_ab.jsonl (tools/step_ab.py, alternating):
+// batch 64 warm / after a cache flush 68.8 / 83.8 us at 12, 68.9 / 85.4 at 8 (previous build 69.6 / 87.0); batch 256
+// 315.7 / 320.5 at 12, 318.4 / 321.7 at 8 (previous build 316.4 / 320.5) -- the memory system's ceiling either way.
+VQA_KNOB g_opt_blocks_per_cu = 12;
 // option 1: bit0 = nt loads of the second stream (the gradient: read exactly once), bit1 = nt stores of the result,
 // bit2 = nt loads of the first and third stream (x, x0), bit3 = nt stores only when the result is larger than the
 // 256 MB Infinity Cache (a smaller result is re-read from the cache by the white box's next forward; a larger one
@@ -109,7 +113,39 @@ __global__ __launch_bounds__(kBlock) void stream4_kernel(const f32x4* s0,  // ma
   size_t last = chunk ? first + chunk : n4;
   if (last > n4) last = n4;
   bool bad = false;
-  for (size_t base = first; base < last; base += stride) {
+  // Whole tiles first, in a loop of their own WITHOUT a branch around any load or store: the compiler counts a wave's
+  // outstanding loads and stores in one counter and, behind a per-lane `i < last` guard, no longer knows how many are
+  // younger than the one it needs -- the guarded form of this loop waited for the first of three loads before issuing
+  // the fourth, and for every store to be acknowledged before computing the next 16 bytes (tools/isa_loop_mix.py --src
+  // linf.hip --waits).  Here a tile's 3 U loads are issued back to back, consumed in order with exact waits, and its U
+  // stores leave together.  Only the last tile of the buffer can be partial; it takes the guarded form below.
+  size_t base = first;
+  for (; base + tile <= last; base += stride) {
+    f32x4 v0[U], v1[U], v2[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+      v0[u] = (NT & 4) ? __builtin_nontemporal_load(&s0[i]) : s0[i];
+      if (Op::kIn > 1) v1[u] = (NT & 1) ? __builtin_nontemporal_load(&s1[i]) : s1[i];
+      if (Op::kIn > 2) v2[u] = (NT & 4) ? __builtin_nontemporal_load(&s2[i]) : s2[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);    // every load of the tile is in flight before the first one is waited for
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        r[u][k] = Op::apply(p, v0[u][k], Op::kIn > 1 ? v1[u][k] : 0.0f, Op::kIn > 2 ? v2[u][k] : 0.0f, bad);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+      if (NT & 2)
+        __builtin_nontemporal_store(r[u], &out[i]);
+      else
+        out[i] = r[u];
+    }
+  }
+  if (base < last) {                      // the partial tile
     f32x4 v0[U], v1[U], v2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
