@@ -171,6 +171,7 @@ def cos_section(b):
             n_layers, nt, "nt" if nt & 1 else "plain", "nt" if nt & 2 else "plain", "nt" if nt & 4 else "plain"),
             12 * rows * 768 * n_layers,
             timeit(lambda: ops.neg_cos_rows_multi(al, tl, slot, accumulate=False, ws=ws), reps=10), "A/B knob sweep")
+    _hip.set_option(8, -1)                    # back to the shipped rule (nt mask by launch size)
     for per_cu, inflight in ((0, 1), (8, 2), (8, 1), (0, 2)):
         if not (_hip.set_option(6, per_cu) and _hip.set_option(7, inflight)):
             break

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __res
 // launch shape (VQA_KNOB: compile-time constants in the shipped library, see common.hpp)
 VQA_KNOB g_loss_blocks_per_cu = 0;   // option 6: 0 = exactly the resident workgroups, n > 0 = n per CU
 VQA_KNOB g_loss_rows_in_flight = 2;  // option 7: 1 | 2
-VQA_KNOB g_loss_nt = 4;              // option 8: bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b
+VQA_KNOB g_loss_nt = -1;             // option 8: bit0 nt loads of a, bit1 nt stores of grad, bit2 nt loads of b; -1 = by size
 VQA_KNOB g_loss_full_rows = 1;       // option 12: rows of NCH * 256 floats take neg_cos_rows_full_kernel (0: the general one)
 
 template <int NCH, bool GRAD, bool PIPE2, int NT>
@@ -401,16 +401,22 @@ static int launch_cos(bool grad, hipStream_t st, const LayerTable& tab, float* p
 #ifdef VQA_TUNING
   if (!grad) return g_loss_rows_in_flight == 2 ? VQA_COS_GO(false, true, 4) : VQA_COS_GO(false, false, 4);
   if (g_loss_rows_in_flight != 2) return VQA_COS_GO(true, false, 4);
-  switch (g_loss_nt) {          // A/B knob of the loss + gradient kernel (two rows in flight)
+  switch (g_loss_nt) {          // A/B knob of the loss + gradient kernel (two rows in flight); -1 = the shipped rule
     case 0: return VQA_COS_GO(true, true, 0);
+    case 4: return VQA_COS_GO(true, true, 4);
     case 5: return VQA_COS_GO(true, true, 5);
     case 6: return VQA_COS_GO(true, true, 6);
     case 7: return VQA_COS_GO(true, true, 7);
-    default: return VQA_COS_GO(true, true, 4);
+    default: break;
   }
-#else       // shipped: two rows in flight per wave, non-temporal loads of the targets only
-  return grad ? VQA_COS_GO(true, true, 4) : VQA_COS_GO(false, true, 4);
 #endif
+  // Shipped: two rows in flight per wave; non-temporal loads of the targets, and -- once a launch moves more than the
+  // 256 MB Infinity Cache can hold (the step kernel's rule) -- of the features and non-temporal gradient stores as well:
+  // inside the attack (13 maps, 4.5 GB) 845 -> 825 us per launch, end to end unchanged
+  // (profiles/r06/loss/loss_nt_insitu.jsonl); a small launch keeps its gradient in the cache for the backward.
+  const long total_bytes = static_cast<long>(ra.rows0) * ra.rows1 * ra.n_layers * D * 12;
+  if (grad && total_bytes > (256L << 20)) return VQA_COS_GO(true, true, 7);
+  return grad ? VQA_COS_GO(true, true, 4) : VQA_COS_GO(false, true, 4);
 #undef VQA_COS_GO
 }
 
@@ -472,7 +478,7 @@ int vqa_loss_set_option(int which, int value) {     // reached through vqa_set_o
     return VQA_OK;
   }
   if (which == 8) {
-    if (value != 0 && value != 4 && value != 5 && value != 6 && value != 7) return VQA_ERR_SHAPE;
+    if (value != -1 && value != 0 && value != 4 && value != 5 && value != 6 && value != 7) return VQA_ERR_SHAPE;
     g_loss_nt = value;
     return VQA_OK;
   }
