@@ -30,19 +30,16 @@ def assembly(src="attn.hip"):
     return out
 
 
-def main():
-    args = sys.argv[1:]
-    src = args[args.index("--src") + 1] if "--src" in args else "attn.hip"
-    files = [a for a in args if a.endswith(".s")]
-    path = files[0] if files else assembly(src)
-    verbose, waits = "-v" in args, "--waits" in args
+def kernels(path):
+    """Per kernel of an assembly file: (demangled name, {NumVgprs, Occupancy, ScratchSize}, loop body text)."""
     text = open(path).read()
     for k in re.split(r"\n(?=_ZN3vqa[^\n]*:\s+; @)", text):
         name = k.split(":")[0]
         if not name.startswith("_ZN3vqa"):
             continue
         demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.split("(")[0].strip()
-        get = lambda key: (re.search(r"; %s: (\d+)" % key, k) or [None, "?"])[1]      # noqa: E731
+        demangled = demangled[5:] if demangled.startswith("void ") else demangled
+        meta = {key: (re.search(r"; %s: (\d+)" % key, k) or [None, "?"])[1] for key in ("NumVgprs", "Occupancy", "ScratchSize")}
         # basic blocks start at a label or a "; %bb.N:" comment; those of a loop say "Loop Header" / "in Loop:"
         body, inside = [], False
         for line in k.split("\n"):
@@ -50,33 +47,47 @@ def main():
                 inside = "Loop Header" in line or "in Loop:" in line
             elif inside:
                 body.append(line)
-        body = "\n".join(body)
+        yield demangled, meta, "\n".join(body)
+
+
+def memory_sequence(body):
+    """The loop's vector memory instructions and vmcnt waits in layout order: L, S, A(tomic), wN, | (barrier)."""
+    seq = []
+    for line in body.split("\n"):
+        t = line.split()
+        if not t or not line.startswith("\t"):
+            continue
+        if t[0].startswith(("global_load", "buffer_load")):
+            seq.append("L")
+        elif t[0].startswith(("global_store", "buffer_store")):
+            seq.append("S")
+        elif t[0].startswith(("global_atomic", "buffer_atomic")):
+            seq.append("A")
+        elif t[0] == "s_waitcnt" and "vmcnt" in line:
+            seq.append("w" + re.search(r"vmcnt\((\d+)\)", line).group(1))
+        elif t[0] == "s_barrier":
+            seq.append("|")
+    return seq
+
+
+def main():
+    args = sys.argv[1:]
+    src = args[args.index("--src") + 1] if "--src" in args else "attn.hip"
+    files = [a for a in args if a.endswith(".s")]
+    path = files[0] if files else assembly(src)
+    verbose, waits = "-v" in args, "--waits" in args
+    for demangled, meta, body in kernels(path):
         ins = [l.split()[0] for l in body.split("\n") if l.startswith("\t") and l.split() and not l.strip().startswith(";")]
         valu = [x for x in ins if x.startswith("v_") and not x.startswith("v_mfma")]
         slow = [x for x in valu if x.startswith(("v_mul_lo", "v_mul_hi", "v_mad_u64", "v_mad_i64"))]
         print("{:<62} vgpr {:>3} occ {} scratch {} | loop: mfma {:>3} valu {:>3} (slow {:>2}) lds {:>3} vmem {:>2}".format(
-            demangled[5:], get("NumVgprs"), get("Occupancy"), get("ScratchSize"),
+            demangled, meta["NumVgprs"], meta["Occupancy"], meta["ScratchSize"],
             sum(x.startswith("v_mfma") for x in ins), len(valu), len(slow), sum(x.startswith("ds_") for x in ins),
             sum(x.startswith(("global_", "buffer_")) for x in ins)))
         if verbose and body:
             print("    " + ", ".join("{} {}".format(n, c) for n, c in collections.Counter(valu).most_common()))
         if waits and body:
-            seq = []
-            for line in body.split("\n"):
-                t = line.split()
-                if not t or not line.startswith("\t"):
-                    continue
-                if t[0].startswith(("global_load", "buffer_load")):
-                    seq.append("L")
-                elif t[0].startswith(("global_store", "buffer_store")):
-                    seq.append("S")
-                elif t[0].startswith(("global_atomic", "buffer_atomic")):
-                    seq.append("A")
-                elif t[0] == "s_waitcnt" and "vmcnt" in line:
-                    seq.append("w" + re.search(r"vmcnt\((\d+)\)", line).group(1))
-                elif t[0] == "s_barrier":
-                    seq.append("|")
-            print("    " + " ".join(seq))
+            print("    " + " ".join(memory_sequence(body)))
 
 
 if __name__ == "__main__":
