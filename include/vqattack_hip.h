@@ -157,7 +157,8 @@ int vqa_scale_per_sample(const float* t, const float* stat, const float* stat2, 
  * partial[] and, when ga != NULL, writes d(gscale * sum(-c)) / d a  into ga (same addressing as a, with its own
  * strides) -- loss value and the gradient w.r.t. the model output in ONE pass over a and b.
  * row_mask (nullable, uint8 row WEIGHTS): row (o, i) is weighted by w = row_mask[(o % mask_period) * rows1 + i];
- * w == 0 rows are not even loaded and get a zero gradient (padded text tokens of a batched adapter), w == 2 counts a
+ * w == 0 rows contribute nothing and get a zero gradient whatever they hold, NaN included (padded text tokens of a
+ * batched adapter; they must be readable: the kernel for rows of 256, 512, ... floats reads them), w == 2 counts a
  * row twice (the VLMO loss takes the [CLS] row both on its own and as a token, V-ch/attacks/fast_gradient_method.py:111).
  * Replaces nn.CosineSimilarity + negate + two torch.sum calls and their autograd backward:
  * A-ch/attacks/fast_gradient_method.py:98,120-127; V-ch/attacks/fast_gradient_method.py:102-114.
