@@ -74,6 +74,12 @@ def test_attention_stores_follow_the_lds_publish_and_nothing_waits_for_them_insi
         last_store = max(i for i, s in enumerate(body) if s == "S")
         assert not any(s.startswith("w") for s in body[body.index("S"):last_store]), (name, seq)   # stores in one group ...
         assert all(s == "S" for s in body[body.index("S"):]), (name, seq)                          # ... at the tile's end
+        # the tile prefetch at the top of the loop is issued without a wait between its loads (a register allocation that
+        # puts the prefetch addresses into the previous tile's load registers brings write-after-write waits -- for the
+        # previous tile's stores -- in between: seen once with non-temporal stores, profiles/r06/attention/ab_8...)
+        first = body.index("L")
+        eighth = [i for i, x in enumerate(body) if x == "L"][7]
+        assert not any(x.startswith("w") for x in body[first:eighth]), (name, seq)
         assert meta["ScratchSize"] == "0"
     # occupancy the launch shapes rely on: 3 waves per SIMD forward, 2 for the key-block kernel
     assert loops["vqa::attn_fwd_kernel<true, true, false>"][0]["Occupancy"] == "3"
