@@ -586,7 +586,7 @@ def stream_probe(nbytes=452984832, reps=12):
     fn.restype = ctypes.c_double
     fn.argtypes = [ctypes.c_int, ctypes.c_size_t] + [ctypes.c_int] * 5
     torch.cuda.synchronize()
-    shapes = [(8, 4, 0), (8, 4, 1), (8, 4, 3), (16, 8, 3), (32, 4, 0), (16, 4, 1)]       # (workgroups per CU, unroll, nt)
+    shapes = [(8, 4, 0), (8, 4, 1), (8, 4, 3), (12, 4, 1), (12, 4, 3), (16, 8, 3), (32, 4, 0), (16, 4, 1)]   # (WG per CU, unroll, nt)
     out = {}
     for name, op, streams in (("step_like_3r1w", 3, 4), ("copy_1r1w", 2, 2)):
         best = max(((fn(op, nbytes, per_cu, unroll, nt, 0, reps), (per_cu, unroll, nt)) for per_cu, unroll, nt in shapes))

@@ -25,7 +25,37 @@ __global__ __launch_bounds__(kBlock) void stream_kernel(const f32x4* __restrict_
   size_t last = chunk ? first + chunk : n4;
   if (last > n4) last = n4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (size_t base = first; base < last; base += stride) {
+  // Whole tiles in a loop without a branch around a load or store (all loads of a tile in flight, exact vmcnt waits, the
+  // stores together) -- the structure csrc/linf.hip has since round 6; with per-lane guards in the loop the compiler's
+  // waits serialise the loads and the stores of a tile, and a "plain stream" probe must not be handicapped that way.
+  size_t base = first;
+  for (; base + tile <= last; base += stride) {
+    f32x4 va[U], vb[U], vc[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+      if (OP != 1) va[u] = (NT & 1) ? __builtin_nontemporal_load(&a[i]) : a[i];
+      if (OP >= 3) vb[u] = (NT & 1) ? __builtin_nontemporal_load(&b[i]) : b[i];
+      if (OP == 3) vc[u] = (NT & 1) ? __builtin_nontemporal_load(&c[i]) : c[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (OP == 0) acc += va[u];
+      if (OP == 1) r[u] = f32x4{1.f, 2.f, 3.f, 4.f};
+      if (OP == 2) r[u] = va[u];
+      if (OP == 3) r[u] = va[u] + vb[u] * vc[u];
+      if (OP == 4) r[u] = va[u] + vb[u];
+    }
+    if (OP != 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t i = base + static_cast<size_t>(u) * kBlock + threadIdx.x;
+        if (NT & 2) __builtin_nontemporal_store(r[u], &out[i]); else out[i] = r[u];
+      }
+    }
+  }
+  if (base < last) {                        // the partial tile
     f32x4 va[U], vb[U], vc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
